@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""ORACLE -- test infrastructure only.  Generates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+
+    python oracle/gen_golden.py
+
+What is imported / executed from the reference (read-only, nothing is copied into the repo):
+  * mmcv/mmcv/ops/multi_scale_deform_attn.py:100-159  ``multi_scale_deformable_attn_pytorch``
+    -- AST-extracted (``import mmcv`` needs the compiled ``_ext``), exec'd with {torch, F}.
+  * visionllmv2/model/internvit/{modeling_intern_vit,configuration_intern_vit}.py -- imported with a
+    6-line identity ``timm.models.layers.DropPath`` stub (``_naive_attn`` + python ``InternRMSNorm`` path).
+  * visionllmv2/model/modeling_visionllmv2.py:381-392 ``pixel_shuffle`` -- AST-extracted method.
+  * visionllmv2/mm_utils.py:23-77 ``find_closest_aspect_ratio`` / ``dynamic_preprocess`` -- AST-extracted,
+    run with a 2-method fake PIL image (only the tile count / grid is recorded).
+  * transformers.CLIPVisionModel (third-party class the reference instantiates at
+    modeling_visionllmv2.py:135; local transformers version recorded in the fixture).
+
+The MSDA known-answer inputs are the reference's own: mmcv/tests/test_ops/test_ms_deformable_attn.py:53-134
+(N,M,D=1,2,2; Lq,L,P=2,2,2; shapes [(6,4),(3,2)]; torch.manual_seed(3); value=rand*0.01; ...).
+"""
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference/VisionLLMv2"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def ast_extract(path, names, glb):
+    src = open(path).read()
+    tree = ast.parse(src)
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in found:
+            node.decorator_list = []
+            mod = ast.Module(body=[node], type_ignores=[])
+            ast.fix_missing_locations(mod)
+            exec(compile(mod, path, "exec"), glb)
+            found[node.name] = glb[node.name]
+    missing = set(names) - set(found)
+    assert not missing, missing
+    return found
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_msda():
+    glb = {"torch": torch, "F": F}
+    fn = ast_extract(f"{REF}/mmcv/mmcv/ops/multi_scale_deform_attn.py",
+                     ["multi_scale_deformable_attn_pytorch"], glb)["multi_scale_deformable_attn_pytorch"]
+
+    def case(name, N, M, D, Lq, shapes, P, seed, mode="kat", dtype=torch.float32):
+        shapes_t = torch.as_tensor(shapes, dtype=torch.long)
+        L = len(shapes)
+        S = int(sum(h * w for h, w in shapes))
+        torch.manual_seed(seed)
+        if mode == "kat":  # exactly the reference test's recipe
+            value = torch.rand(N, S, M, D) * 0.01
+            loc = torch.rand(N, Lq, M, L, P, 2)
+            w = torch.rand(N, Lq, M, L, P) + 1e-5
+            w /= w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        else:  # stress: out-of-range / border locations, signed values
+            value = torch.randn(N, S, M, D)
+            loc = torch.rand(N, Lq, M, L, P, 2) * 1.3 - 0.15
+            # force a few exact-border / exact-pixel-centre cases
+            flat = loc.view(-1)
+            flat[0::97] = 0.0
+            flat[1::101] = 1.0
+            flat[2::103] = 0.5
+            w = torch.softmax(torch.randn(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        out32 = fn(value, shapes_t, loc, w).detach()
+        out64 = fn(value.double(), shapes_t, loc.double(), w.double()).detach()
+        lsi = torch.cat((shapes_t.new_zeros((1,)), shapes_t.prod(1).cumsum(0)[:-1]))
+        np.savez_compressed(os.path.join(OUT, f"msda_{name}.npz"),
+                            value=value.numpy(), shapes=shapes_t.numpy(), lsi=lsi.numpy(),
+                            loc=loc.numpy(), attw=w.numpy(),
+                            out_f32=out32.numpy(), out_f64=out64.numpy(),
+                            torch_version=np.array(torch.__version__))
+        print(f"msda_{name}: out shape {tuple(out32.shape)}  f64[0,0,:4]={out64[0, 0, :4].tolist()}")
+
+    case("kat_seed3", 1, 2, 2, 2, [(6, 4), (3, 2)], 2, 3, "kat")
+    case("stress_small", 2, 4, 8, 37, [(7, 5), (4, 3), (2, 2)], 3, 11, "stress")
+    case("stress_d32", 2, 8, 32, 50, [(12, 10), (6, 5), (3, 3), (2, 1)], 4, 12, "stress")
+    case("odd_channels", 1, 3, 5, 19, [(5, 6), (3, 3)], 2, 13, "stress")
+
+
+# --------------------------------------------------------------------------------------------------
+def load_intern_vit():
+    import transformers.activations, transformers.modeling_outputs, transformers.modeling_utils  # noqa: F401 (before the stub)
+    import transformers.configuration_utils  # noqa: F401
+    timm = types.ModuleType("timm"); models = types.ModuleType("timm.models"); layers = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):  # identity stub (eval-mode semantics of timm DropPath)
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+    layers.DropPath = DropPath
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+    pkg = types.ModuleType("refvit"); pkg.__path__ = [f"{REF}/visionllmv2/model/internvit"]
+    sys.modules["refvit"] = pkg
+    mods = {}
+    for name in ("configuration_intern_vit", "modeling_intern_vit"):
+        spec = importlib.util.spec_from_file_location(f"refvit.{name}", f"{REF}/visionllmv2/model/internvit/{name}.py")
+        m = importlib.util.module_from_spec(spec); sys.modules[f"refvit.{name}"] = m
+        spec.loader.exec_module(m); mods[name] = m
+    return mods["configuration_intern_vit"].InternVisionConfig, mods["modeling_intern_vit"].InternVisionModel
+
+
+def gen_intern_vit():
+    Cfg, Model = load_intern_vit()
+
+    def case(name, seed, **kw):
+        cfg = Cfg(use_flash_attn=False, **kw)
+        torch.manual_seed(seed)
+        model = Model(cfg).eval().float()
+        with torch.no_grad():  # make every parameter non-trivial so a swapped/missing one is caught
+            for n_, p in model.named_parameters():
+                if n_.endswith("norm1.weight") or n_.endswith("norm2.weight") or "q_norm" in n_ or "k_norm" in n_:
+                    p.copy_(1.0 + 0.2 * torch.randn_like(p))
+                elif n_.endswith("ls1") or n_.endswith("ls2"):
+                    p.copy_(0.1 + 0.05 * torch.randn_like(p))
+                elif n_.endswith(".bias"):
+                    p.copy_(0.1 * torch.randn_like(p))
+                elif "class_embedding" in n_ or "position_embedding" in n_:
+                    p.copy_(0.5 * torch.randn_like(p))
+        x = torch.randn(2, 3, cfg.image_size, cfg.image_size)
+        with torch.no_grad():
+            out = model(x, output_hidden_states=True, return_dict=True)
+        hs = torch.stack(out.hidden_states, 0)
+        cfgd = {k: getattr(cfg, k) for k in ("hidden_size", "num_attention_heads", "num_hidden_layers", "patch_size",
+                                             "image_size", "intermediate_size", "layer_norm_eps",
+                                             "qk_normalization", "qkv_bias", "hidden_act")}
+        np.savez_compressed(os.path.join(OUT, f"internvit_{name}.npz"), pixel_values=x.numpy(),
+                            hidden_states=hs.numpy(), last_hidden_state=out.last_hidden_state.numpy(),
+                            cfg=np.array(repr(cfgd)), **{"sd." + k: v for k, v in np_sd(model.state_dict()).items()})
+        print(f"internvit_{name}: hs {tuple(hs.shape)} |hs[-1]| max {hs[-1].abs().max():.3f}")
+
+    case("tiny_qknorm", 0, hidden_size=64, num_attention_heads=2, intermediate_size=128, num_hidden_layers=3,
+         image_size=28, patch_size=14, qk_normalization=True, qkv_bias=False)
+    case("tiny_bias", 1, hidden_size=64, num_attention_heads=4, intermediate_size=96, num_hidden_layers=2,
+         image_size=42, patch_size=14, qk_normalization=False, qkv_bias=True)
+    # GPU-kernel-shaped case: d=64 heads, S=17 (tails everywhere), K multiple of 64
+    case("small_d64", 2, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+         image_size=56, patch_size=14, qk_normalization=True, qkv_bias=False)
+
+
+def gen_clip():
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+
+    def case(name, seed, **kw):
+        cfg = CLIPVisionConfig(**kw)
+        try:
+            cfg._attn_implementation = "eager"
+        except Exception:
+            pass
+        torch.manual_seed(seed)
+        model = CLIPVisionModel(cfg).eval().float()
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if "layer_norm" in n_ or "layrnorm" in n_:
+                    p.copy_((1.0 if n_.endswith("weight") else 0.0) + 0.2 * torch.randn_like(p))
+                elif n_.endswith(".bias"):
+                    p.copy_(0.1 * torch.randn_like(p))
+                elif "embedding" in n_:
+                    p.copy_(0.5 * torch.randn_like(p))
+                else:
+                    p.copy_(0.08 * torch.randn_like(p))
+        x = torch.randn(2, 3, cfg.image_size, cfg.image_size)
+        with torch.no_grad():
+            out = model(pixel_values=x, output_hidden_states=True, return_dict=True)
+        hs = torch.stack(out.hidden_states, 0)
+        cfgd = {k: getattr(cfg, k) for k in ("hidden_size", "num_attention_heads", "num_hidden_layers", "patch_size",
+                                             "image_size", "intermediate_size", "layer_norm_eps", "hidden_act")}
+        np.savez_compressed(os.path.join(OUT, f"clip_{name}.npz"), pixel_values=x.numpy(), hidden_states=hs.numpy(),
+                            cfg=np.array(repr(cfgd)), transformers_version=np.array(transformers.__version__),
+                            **{"sd." + k: v for k, v in np_sd(model.state_dict()).items()})
+        print(f"clip_{name}: hs {tuple(hs.shape)} keys e.g. {list(model.state_dict())[:3]}")
+
+    case("tiny", 0, hidden_size=64, num_attention_heads=2, intermediate_size=128, num_hidden_layers=3,
+         image_size=28, patch_size=14, hidden_act="quick_gelu")
+    case("small_d64", 1, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+         image_size=56, patch_size=14, hidden_act="quick_gelu")
+
+
+def gen_bridge():
+    glb = {"torch": torch, "int": int}
+    ps = ast_extract(f"{REF}/visionllmv2/model/modeling_visionllmv2.py", ["pixel_shuffle"], glb)["pixel_shuffle"]
+    torch.manual_seed(5)
+    x = torch.randn(3, 8, 8, 12)
+    y = ps(None, x, scale_factor=0.5)
+    # bridges constructed exactly as modeling_visionllmv2.py:162-182 does (torch's own modules)
+    feats = torch.randn(2, 16, 48)
+    torch.manual_seed(6)
+    lin = nn.Linear(48, 40)
+    mlp2 = nn.Sequential(nn.Linear(48, 40), nn.GELU(), nn.Linear(40, 40))
+    ivl = nn.Sequential(nn.LayerNorm(48), nn.Linear(48, 40), nn.GELU(), nn.Linear(40, 40))
+    with torch.no_grad():
+        ivl[0].weight.copy_(1 + 0.2 * torch.randn(48)); ivl[0].bias.copy_(0.1 * torch.randn(48))
+        outs = {"linear": lin(feats), "mlp2x_gelu": mlp2(feats), "internvl_mlp": ivl(feats)}
+    save = {"ps_in": x.numpy(), "ps_out": y.numpy(), "feats": feats.numpy()}
+    for kind, mod in (("linear", lin), ("mlp2x_gelu", mlp2), ("internvl_mlp", ivl)):
+        save[f"out.{kind}"] = outs[kind].numpy()
+        for k, v in np_sd(mod.state_dict()).items():
+            save[f"sd.{kind}.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "bridge.npz"), **save)
+    print("bridge: pixel_shuffle", tuple(x.shape), "->", tuple(y.shape))
+
+
+def gen_tiling():
+    glb = {}
+    fns = ast_extract(f"{REF}/visionllmv2/mm_utils.py", ["find_closest_aspect_ratio", "dynamic_preprocess"], glb)
+
+    class FakeImg:
+        def __init__(self, w, h):
+            self.size = (w, h)
+
+        def resize(self, wh):
+            return FakeImg(*wh)
+
+        def crop(self, box):
+            return FakeImg(box[2] - box[0], box[3] - box[1])
+
+    rows = []
+    for (w, h) in [(1336, 1336), (640, 480), (480, 640), (1920, 1080), (300, 1200), (336, 336), (1000, 333), (800, 800)]:
+        for (isz, mx) in [(336, 4), (448, 6)]:
+            tiles = fns["dynamic_preprocess"](FakeImg(w, h), min_num=1, max_num=mx, image_size=isz, use_thumbnail=True)
+            rows.append((w, h, isz, mx, len(tiles)))
+    np.savez_compressed(os.path.join(OUT, "tiling.npz"), rows=np.array(rows, dtype=np.int64))
+    print("tiling:", rows[:2])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_msda()
+    gen_intern_vit()
+    gen_clip()
+    gen_bridge()
+    gen_tiling()

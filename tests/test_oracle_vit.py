@@ -1,0 +1,55 @@
+"""The torch restatement of the ViT / bridge / tiling path is pinned against fixtures produced by the
+reference classes themselves (oracle/gen_golden.py).  CPU only."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_sd, load_golden
+from oracle import vit as V
+
+
+def _cfg(g):
+    return ast.literal_eval(str(g["cfg"]))
+
+
+@pytest.mark.parametrize("name", ["internvit_tiny_qknorm.npz", "internvit_tiny_bias.npz", "internvit_small_d64.npz"])
+def test_intern_vit_restatement(name):
+    g = load_golden(name)
+    hs = V.intern_vit_forward(golden_sd(g), _cfg(g), torch.from_numpy(g["pixel_values"]))
+    ref = g["hidden_states"]
+    assert len(hs) == ref.shape[0] == _cfg(g)["num_hidden_layers"] + 1
+    for i, h in enumerate(hs):
+        np.testing.assert_allclose(h.numpy(), ref[i], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(hs[-1].numpy(), g["last_hidden_state"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["clip_tiny.npz", "clip_small_d64.npz"])
+def test_clip_vit_restatement(name):
+    g = load_golden(name)
+    sd = golden_sd(g)
+    prefix = "vision_model." if any(k.startswith("vision_model.") for k in sd) else ""
+    hs = V.clip_vit_forward(sd, _cfg(g), torch.from_numpy(g["pixel_values"]), prefix=prefix)
+    ref = g["hidden_states"]
+    assert len(hs) == ref.shape[0]
+    for i, h in enumerate(hs):
+        np.testing.assert_allclose(h.numpy(), ref[i], rtol=2e-5, atol=2e-5)
+
+
+def test_pixel_shuffle_and_bridges():
+    g = load_golden("bridge.npz")
+    y = V.pixel_shuffle(torch.from_numpy(g["ps_in"]), 0.5)
+    assert np.array_equal(y.numpy(), g["ps_out"])  # pure data movement: bit-exact
+    feats = torch.from_numpy(g["feats"])
+    for kind in ("linear", "mlp2x_gelu", "internvl_mlp"):
+        sd = golden_sd(g, prefix=f"sd.{kind}.")
+        out = V.bridge_forward(sd, kind, feats)
+        np.testing.assert_allclose(out.numpy(), g[f"out.{kind}"], rtol=1e-5, atol=1e-6)
+
+
+def test_tile_grid():
+    rows = load_golden("tiling.npz")["rows"]
+    for w, h, isz, mx, n in rows.tolist():
+        assert V.tile_grid(w, h, 1, mx, isz, True)[2] == n
+    assert V.tile_grid(1336, 1336, 1, 4, 336)[2] == 5 and V.tile_grid(1336, 1336, 1, 6, 448)[2] == 5
