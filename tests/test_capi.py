@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/vllm_hip.h declares (no compute)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from visionllm_amd import _lib
+
+
+def test_header_parses_and_names_are_prefixed():
+    protos = _lib.parse_header()
+    assert "vllm_msda_forward_f32" in protos and "vllm_last_error" in protos
+    assert all(n.startswith("vllm_") for n in protos)
+
+
+def test_library_exports_every_declared_symbol():
+    path = _lib.lib_path()
+    if not os.path.exists(path):
+        _lib.build()
+    raw = ctypes.CDLL(path)
+    missing = [n for n in _lib.parse_header() if not hasattr(raw, n)]
+    assert not missing, missing
+    L = _lib.lib()
+    assert L.vllm_abi_version() == 1
+
+
+def test_no_undeclared_exports():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.lib_path()], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T vllm_" in line}
+    assert exported == set(_lib.parse_header()), exported ^ set(_lib.parse_header())
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(root, "visionllm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                if "import oracle" in src or "from oracle" in src or "oracle/" in src.replace("oracle/ ", ""):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    import torch
+    from visionllm_amd.ms_deform_attn import ms_deform_attn_forward
+    v = torch.zeros(1, 6, 2, 4)
+    with pytest.raises(RuntimeError):
+        ms_deform_attn_forward(v, torch.tensor([[2, 3]]), torch.tensor([0]), torch.zeros(1, 1, 2, 1, 2, 2),
+                               torch.zeros(1, 1, 2, 1, 2), 64)
+
+
+def test_module_constructor_errors_mirror_reference():
+    # mmcv/tests/test_ops/test_ms_deformable_attn.py:25-30
+    from visionllm_amd.ms_deform_attn import MSDeformAttn, MultiScaleDeformableAttention
+    with pytest.raises(ValueError):
+        MultiScaleDeformableAttention(embed_dims=256, num_heads=7)
+    with pytest.raises(ValueError):
+        MSDeformAttn(d_model=256, n_heads=7)

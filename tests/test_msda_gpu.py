@@ -1,0 +1,199 @@
+"""GPU parity tests for the MSDA operator: HIP (through the C ABI) vs the CPU oracle / golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from msda_inputs import CFG4_SHAPES, make_inputs
+from oracle import msda as O
+from visionllm_amd import ms_deform_attn as A
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def _run(g, dtype=torch.float32):
+    fd = dtype if dtype != torch.bfloat16 else torch.float32
+    return A.ms_deform_attn_forward(_t(g["value"], dtype), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"], fd),
+                                    _t(g["attw"], fd), 64)
+
+
+GOLD = ["msda_kat_seed3.npz", "msda_stress_small.npz", "msda_stress_d32.npz", "msda_odd_channels.npz"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_forward_f64_vs_reference_golden(name):
+    g = load_golden(name)
+    out = _run(g, torch.float64).cpu().numpy()
+    np.testing.assert_allclose(out, g["out_f64"], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_forward_f32_vs_reference_golden(name):
+    g = load_golden(name)
+    out = _run(g, torch.float32).cpu().numpy().astype(np.float64)
+    ref = g["out_f64"]
+    err = np.abs(out - ref).max()
+    if name == "msda_kat_seed3.npz":
+        # the reference's own float thresholds (test_ms_deformable_attn.py:129-134)
+        assert err < 1e-9 and (np.abs(out - ref) / np.abs(ref)).max() < 1e-6
+    assert err <= 2e-6 * max(np.abs(ref).max(), 1e-3)
+
+
+@pytest.mark.parametrize("mode,D,M,P", [("encoder_like", 32, 8, 4), ("stress", 32, 8, 4), ("stress", 16, 4, 2),
+                                         ("stress", 64, 2, 8), ("stress", 4, 3, 1), ("stress", 128, 2, 4),
+                                         ("stress", 20, 2, 3), ("stress", 256, 1, 4)])
+def test_forward_f32_vs_oracle_and_index_exact(mode, D, M, P):
+    shapes = [(21, 19), (11, 10), (6, 5), (3, 3)]
+    g = make_inputs(3, M, D, shapes, P, Lq=None if mode == "encoder_like" else 333, mode=mode, seed=D + P)
+    out = _run(g).cpu().numpy()
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
+    # integer part: exact
+    h, w, mk = A.sample_index(_t(g["shapes"]), _t(g["loc"]))
+    ho, wo, mo = O.sample_index(g["shapes"], g["loc"])
+    assert np.array_equal(mk.cpu().numpy(), mo)
+    assert np.array_equal(h.cpu().numpy(), ho) and np.array_equal(w.cpu().numpy(), wo)
+
+
+def test_forward_bf16_variant():
+    shapes = [(21, 19), (11, 10), (6, 5), (3, 3)]
+    g = make_inputs(2, 8, 32, shapes, 4, Lq=200, mode="stress", seed=5)
+    vb = torch.from_numpy(g["value"]).to(torch.bfloat16)
+    out = A.ms_deform_attn_forward(vb.to(DEV), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]), _t(g["attw"]), 64)
+    ref = O.forward(vb.float().numpy(), g["shapes"], g["lsi"], g["loc"], g["attw"])
+    # only the final rounding to bf16 differs: 2^-8 relative
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=8e-3, atol=8e-3)
+
+
+def test_full_size_cfg4_vs_oracle_and_properties():
+    """BASELINE cfg 4 shapes (168^2..21^2, M8 D32 P4), B=2: whole-tensor oracle comparison + linearity."""
+    g = make_inputs(2, 8, 32, CFG4_SHAPES, 4, mode="encoder_like", seed=0)
+    out = _run(g)
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    h, w, mk = A.sample_index(_t(g["shapes"]), _t(g["loc"]))
+    ho, wo, mo = O.sample_index(g["shapes"], g["loc"])
+    assert np.array_equal(mk.cpu().numpy(), mo) and np.array_equal(h.cpu().numpy(), ho) \
+        and np.array_equal(w.cpu().numpy(), wo)
+    # linearity in value: f(2*v + v2) == 2*f(v) + f(v2)
+    v2 = torch.randn_like(_t(g["value"]))
+    g2 = dict(g)
+    lhs = A.ms_deform_attn_forward(2 * _t(g["value"]) + v2, _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]),
+                                   _t(g["attw"]), 64)
+    rhs = 2 * out + A.ms_deform_attn_forward(v2, _t(g2["shapes"]), _t(g2["lsi"]), _t(g2["loc"]), _t(g2["attw"]), 64)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-4, atol=1e-4)
+    # constant value + interior points -> weights sum to one -> output == the constant
+    gi = make_inputs(1, 8, 32, CFG4_SHAPES, 4, Lq=1000, mode="stress", seed=3)
+    loc = np.clip(gi["loc"], 0.2, 0.8)
+    cst = torch.full((1, gi["value"].shape[1], 8, 32), 1.25, device=DEV)
+    o = A.ms_deform_attn_forward(cst, _t(gi["shapes"]), _t(gi["lsi"]), _t(loc), _t(gi["attw"]), 64)
+    torch.testing.assert_close(o, torch.full_like(o, 1.25), rtol=1e-5, atol=1e-5)
+
+
+def test_nonfinite_values_outside_the_footprint_do_not_leak():
+    g = make_inputs(1, 2, 32, [(4, 4)], 4, Lq=16, mode="stress", seed=9)
+    loc = np.full_like(g["loc"], 0.999)  # bottom-right pixel: only corner 1 in bounds
+    v = g["value"].copy()
+    v[0, :15] = np.nan  # every other pixel is NaN; clamped addresses may touch them
+    o = A.ms_deform_attn_forward(_t(v), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]), 64)
+    assert torch.isfinite(o).all()
+    ref = O.forward(v, g["shapes"], g["lsi"], loc, g["attw"])
+    np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_edge_cases_and_errors():
+    shapes = torch.tensor([[2, 3]], device=DEV)
+    lsi = torch.tensor([0], device=DEV)
+    v = torch.zeros(1, 6, 2, 4, device=DEV)
+    out = A.ms_deform_attn_forward(v, shapes, lsi, torch.zeros(1, 0, 2, 1, 2, 2, device=DEV),
+                                   torch.zeros(1, 0, 2, 1, 2, device=DEV), 64)
+    assert out.shape == (1, 0, 8)
+    with pytest.raises(RuntimeError):  # not contiguous
+        A.ms_deform_attn_forward(torch.zeros(1, 6, 4, 2, device=DEV).transpose(2, 3), shapes, lsi,
+                                 torch.zeros(1, 1, 2, 1, 2, 2, device=DEV), torch.zeros(1, 1, 2, 1, 2, device=DEV), 64)
+    with pytest.raises(RuntimeError):  # batch % im2col_step (ms_deform_attn_cuda.cu:50-52)
+        A.ms_deform_attn_forward(torch.zeros(3, 6, 2, 4, device=DEV), shapes, lsi,
+                                 torch.zeros(3, 1, 2, 1, 2, 2, device=DEV), torch.zeros(3, 1, 2, 1, 2, device=DEV), 2)
+    with pytest.raises(RuntimeError):  # cpu tensor
+        A.ms_deform_attn_forward(v.cpu(), shapes, lsi, torch.zeros(1, 1, 2, 1, 2, 2, device=DEV),
+                                 torch.zeros(1, 1, 2, 1, 2, device=DEV), 64)
+
+
+@pytest.mark.parametrize("channels", [4, 30, 32, 64, 71, 1025])  # the reference's gradcheck list (:139-146)
+def test_backward_vs_oracle_f64(channels):
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = [(3, 2), (2, 1)]
+    g = make_inputs(N, M, channels, shapes, P, Lq=Lq, mode="stress", seed=channels, dtype=np.float64)
+    g["value"] *= 0.01
+    rng = np.random.default_rng(1)
+    go = rng.standard_normal((N, Lq, M * channels))
+    gv, gl, gw = A.ms_deform_attn_backward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]),
+                                           _t(g["attw"]), _t(go), 2)
+    rv, rl, rw = O.backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"], go)
+    np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gl.cpu().numpy(), rl, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gw.cpu().numpy(), rw, rtol=1e-10, atol=1e-13)
+
+
+def test_backward_f32_and_autograd_function():
+    shapes = [(9, 7), (5, 4)]
+    g = make_inputs(2, 4, 32, shapes, 4, Lq=50, mode="stress", seed=2)
+    v = _t(g["value"]).requires_grad_(True)
+    loc = _t(g["loc"]).requires_grad_(True)
+    w = _t(g["attw"]).requires_grad_(True)
+    out = A.MSDeformAttnFunction.apply(v, _t(g["shapes"]), _t(g["lsi"]), loc, w, 64)
+    go = torch.randn_like(out)
+    out.backward(go)
+    rv, rl, rw = O.backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"], go.cpu().numpy())
+    np.testing.assert_allclose(v.grad.cpu().numpy(), rv, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(loc.grad.cpu().numpy(), rl, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), rw, rtol=1e-4, atol=1e-4)
+
+
+def test_modules_match_oracle_composition():
+    """MSDeformAttn / mmcv module / GDINO module == (torch Linear layers + oracle op) on the same weights."""
+    torch.manual_seed(0)
+    shapes = [(8, 6), (4, 3)]
+    S = 48 + 12
+    mod = A.MSDeformAttn(d_model=64, n_levels=2, n_heads=4, n_points=4).to(DEV)
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.05)
+        mod.attention_weights.weight.normal_(0, 0.5)
+    q = torch.randn(2, 20, 64, device=DEV)
+    src = torch.randn(2, S, 64, device=DEV)
+    ref_pts = torch.rand(2, 20, 2, 2, device=DEV)
+    ss = torch.tensor(shapes, device=DEV)
+    lsi = torch.tensor([0, 48], device=DEV)
+    mask = torch.zeros(2, S, dtype=torch.bool, device=DEV)
+    mask[1, -5:] = True
+    out = mod(q, ref_pts, src, ss, lsi, mask)
+    with torch.no_grad():
+        value = mod.value_proj(src).masked_fill(mask[..., None], 0.0).view(2, S, 4, 16)
+        off = mod.sampling_offsets(q).view(2, 20, 4, 2, 4, 2)
+        aw = torch.softmax(mod.attention_weights(q).view(2, 20, 4, 8), -1).view(2, 20, 4, 2, 4)
+        norm = torch.stack([ss[..., 1], ss[..., 0]], -1)
+        locs = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        core = O.forward(value.cpu().numpy(), ss.cpu().numpy(), lsi.cpu().numpy(), locs.cpu().numpy(), aw.cpu().numpy())
+        expect = mod.output_proj(torch.from_numpy(core).to(DEV))
+    torch.testing.assert_close(out, expect, rtol=1e-4, atol=1e-4)
+    # mmcv module: (num_query, bs, C) layout, identity residual, dropout 0
+    mm = A.MultiScaleDeformableAttention(embed_dims=64, num_heads=4, num_levels=2, num_points=4, dropout=0.0).to(DEV)
+    mm.load_state_dict(mod.state_dict())
+    o2 = mm(q.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts,
+            spatial_shapes=ss, level_start_index=lsi)
+    torch.testing.assert_close(o2.permute(1, 0, 2), expect + q, rtol=1e-4, atol=1e-4)
+
+    class Cfg:
+        d_model, num_feature_levels, disable_custom_kernels = 64, 2, False
+    gd = A.GroundingDinoMultiscaleDeformableAttention(Cfg(), 4, 4).to(DEV)
+    gd.load_state_dict(mod.state_dict())
+    o3, aw3 = gd(q, attention_mask=~mask, encoder_hidden_states=src, reference_points=ref_pts, spatial_shapes=ss,
+                 level_start_index=lsi)
+    torch.testing.assert_close(o3, expect, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(aw3, aw, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""MSDA forward micro-benchmark at BASELINE cfg 4 (run on the GPU box)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from msda_inputs import CFG4_SHAPES, make_inputs  # noqa: E402
+from visionllm_amd import ms_deform_attn as A  # noqa: E402
+
+
+def algorithmic_bytes(B, S, M, D, L, Lq, P, vbytes=4):
+    # value + loc + attw + out
+    return B * S * M * D * vbytes + B * Lq * M * L * P * 2 * 4 + B * Lq * M * L * P * 4 + B * Lq * M * D * vbytes
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--modes", default="encoder_like,stress")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    res = []
+    for mode in a.modes.split(","):
+        for lq in (None, 900):
+            g1 = make_inputs(1, 8, 32, CFG4_SHAPES, 4, Lq=lq if (lq or mode != "stress") else 37485, mode=mode, seed=0)
+            t = {k: torch.from_numpy(v).to(dev) for k, v in g1.items()}
+            for k in ("value", "loc", "attw"):  # replicate batch on device (same distribution, distinct memory)
+                t[k] = t[k].repeat(a.B, *([1] * (t[k].dim() - 1))).contiguous()
+                if k == "value":
+                    t[k] = t[k] + 0.01 * torch.randn_like(t[k])
+            B, S, M, D = t["value"].shape
+            Lq, L, P = t["loc"].shape[1], t["loc"].shape[3], t["loc"].shape[4]
+            for dt in ("f32", "bf16"):
+                v = t["value"] if dt == "f32" else t["value"].bfloat16()
+                sec = timeit(lambda: A.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["attw"], 64), a.iters)
+                ab = algorithmic_bytes(B, S, M, D, L, Lq, P, 4 if dt == "f32" else 2)
+                gathered = B * Lq * M * L * P * 4 * D * (4 if dt == "f32" else 2)
+                r = dict(mode=mode, dtype=dt, B=B, Lq=Lq, us=sec * 1e6, algo_GBs=ab / sec / 1e9,
+                         frac_of_8TBs=ab / sec / 8e12, gathered_TBs=gathered / sec / 1e12)
+                res.append(r)
+                print(json.dumps(r))
+    return res
+
+
+if __name__ == "__main__":
+    main()

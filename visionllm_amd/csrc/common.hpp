@@ -1,0 +1,56 @@
+// Shared host/device helpers for libvllm_hip.so (gfx950 only; no CUDA compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/vllm_hip.h"
+
+namespace vllm {
+
+void set_error(const char *fmt, ...);
+
+#define VLLM_REQUIRE(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::vllm::set_error(__VA_ARGS__);      \
+            return VLLM_EINVAL;                  \
+        }                                        \
+    } while (0)
+
+#define VLLM_CHECK_LAUNCH(what)                                                        \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            ::vllm::set_error("%s: %s", what, hipGetErrorString(e__));                 \
+            return VLLM_ELAUNCH;                                                       \
+        }                                                                              \
+    } while (0)
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 (device) -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t pair) { return __uint_as_float(pair << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t pair) { return __uint_as_float(pair & 0xffff0000u); }
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+
+}  // namespace vllm

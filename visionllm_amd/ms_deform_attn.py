@@ -1,0 +1,407 @@
+"""Multi-scale deformable attention: host-side mirror of the reference operator + module interfaces.
+
+Boundary B3 of SURVEY.md section 8b.  Same names, argument meaning and error behaviour as
+
+* ``MultiScaleDeformableAttention.ms_deform_attn_forward / ms_deform_attn_backward`` -- the pybind module of
+  visionllmv2/model/unipose/ops/src/vision.cpp:13-16 (signatures ms_deform_attn.h:20-61) and the object returned
+  by HF's ``load_cuda_kernels()`` (modeling_ov_grounding_dino_mask_dn.py:110, 147, 170);
+* ``MSDeformAttnFunction``   -- visionllmv2/model/unipose/ops/functions/ms_deform_attn_func.py:21-38
+  (== ``MultiScaleDeformableAttentionFunction``, modeling_ov_grounding_dino_mask_dn.py:134-180);
+* ``MultiScaleDeformableAttnFunction`` (mmcv flavour: fp32 cast, in-place grads) -- mmcv/mmcv/ops/multi_scale_deform_attn.py:23-97;
+* ``MSDeformAttn``           -- visionllmv2/model/unipose/ops/modules/ms_deform_attn.py:34-145;
+* ``MultiScaleDeformableAttention`` (mmcv module) -- mmcv/mmcv/ops/multi_scale_deform_attn.py:162-367;
+* ``GroundingDinoMultiscaleDeformableAttention`` -- modeling_ov_grounding_dino_mask_dn.py:646-784.
+
+The compute is libvllm_hip.so (visionllm_amd/csrc/msda.hip).  Like the reference's native extension
+("Not implement on cpu", src/cpu/ms_deform_attn_cpu.cpp:16-40) the op raises for CPU tensors; unlike the
+reference modules we do NOT silently fall back to a pure-torch path (modeling_ov_grounding_dino_mask_dn.py:777-779
+would mask a broken kernel).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    # mirrors the AT_ASSERTM block of ms_deform_attn_cuda.cu:28-52
+    for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor (ms_deform_attn: Not implemented on the CPU)")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("ms_deform_attn: value [B,S,M,D], sampling_loc [B,Lq,M,L,P,2], attn_weight [B,Lq,M,L,P]")
+    B, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_loc.shape
+    if M2 != M or two != 2 or tuple(attn_weight.shape) != (B, Lq, M, L, P) or sampling_loc.shape[0] != B:
+        raise RuntimeError("ms_deform_attn: inconsistent shapes")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("ms_deform_attn: spatial_shapes / level_start_index must be int64")
+    if tuple(spatial_shapes.shape) != (L, 2) or level_start_index.numel() != L:
+        raise RuntimeError("ms_deform_attn: spatial_shapes must be [L,2] and level_start_index [L]")
+    step = min(B, int(im2col_step)) if B > 0 else 1
+    if step <= 0 or (B > 0 and B % step != 0):
+        raise RuntimeError(f"batch({B}) must divide im2col_step({step})")
+    return B, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """-> Tensor[B, Lq, M*D].  float32 / float64 (as the reference's AT_DISPATCH_FLOATING_TYPES) and, as an
+    extension, bfloat16 value with float32 locations/weights."""
+    B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                         im2col_step)
+    lib = _lib.lib()
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        st = _lib.current_stream(value.device)
+        args = (_lib.ptr(value), _lib.ptr(spatial_shapes), _lib.ptr(level_start_index), _lib.ptr(sampling_loc),
+                _lib.ptr(attn_weight), B, S, M, D, L, Lq, P, _lib.ptr(out), st)
+        if value.dtype == torch.float32:
+            if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
+                raise RuntimeError("ms_deform_attn_forward: all floating inputs must share the value dtype (float32)")
+            _lib.check(lib.vllm_msda_forward_f32(*args), "vllm_msda_forward_f32")
+        elif value.dtype == torch.float64:
+            if sampling_loc.dtype != torch.float64 or attn_weight.dtype != torch.float64:
+                raise RuntimeError("ms_deform_attn_forward: all floating inputs must share the value dtype (float64)")
+            _lib.check(lib.vllm_msda_forward_f64(*args), "vllm_msda_forward_f64")
+        elif value.dtype == torch.bfloat16:
+            if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
+                raise RuntimeError("ms_deform_attn_forward(bf16 value): sampling_loc / attn_weight must be float32")
+            _lib.check(lib.vllm_msda_forward_bf16(*args), "vllm_msda_forward_bf16")
+        else:
+            raise RuntimeError(f"ms_deform_attn_forward: unsupported dtype {value.dtype}")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step=64):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (list, as ms_deform_attn.h:41-61)."""
+    B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                         im2col_step)
+    if not grad_output.is_cuda:
+        raise RuntimeError("grad_output must be a CUDA tensor")
+    grad_output = grad_output.contiguous()
+    if value.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"ms_deform_attn_backward: unsupported dtype {value.dtype}")
+    gv = torch.zeros_like(value)
+    gl = torch.zeros_like(sampling_loc)
+    gw = torch.zeros_like(attn_weight)
+    _backward_into(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, gv, gl, gw,
+                   (B, S, M, D, L, Lq, P))
+    return [gv, gl, gw]
+
+
+def _backward_into(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, gv, gl, gw, dims):
+    B, S, M, D, L, Lq, P = dims
+    lib = _lib.lib()
+    fn = lib.vllm_msda_backward_f32 if value.dtype == torch.float32 else lib.vllm_msda_backward_f64
+    with torch.cuda.device(value.device):
+        _lib.check(fn(_lib.ptr(value), _lib.ptr(spatial_shapes), _lib.ptr(level_start_index), _lib.ptr(sampling_loc),
+                      _lib.ptr(attn_weight), _lib.ptr(grad_output), B, S, M, D, L, Lq, P, _lib.ptr(gv), _lib.ptr(gl),
+                      _lib.ptr(gw), _lib.current_stream(value.device)), "vllm_msda_backward")
+
+
+def ms_deform_attn_backward_(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                             grad_value, grad_sampling_loc, grad_attn_weight, im2col_step=64):
+    """mmcv ``_ext`` flavour: accumulates into caller-provided (zero-filled) gradients
+    (mmcv/ops/csrc/pytorch/ms_deform_attn.cpp:48-60)."""
+    dims = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    _backward_into(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output.contiguous(),
+                   grad_value, grad_sampling_loc, grad_attn_weight, dims)
+
+
+def sample_index(spatial_shapes, sampling_loc):
+    """Parity tooling: integer part of the sampling (h_low, w_low, mask) computed by the kernels' own device
+    function.  mask bit0 = point accepted, bits 1-4 = corner 1..4 in bounds."""
+    B, Lq, M, L, P, _ = sampling_loc.shape
+    dev = sampling_loc.device
+    h = torch.empty((B, Lq, M, L, P), dtype=torch.int32, device=dev)
+    w = torch.empty_like(h)
+    mk = torch.empty((B, Lq, M, L, P), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vllm_msda_sample_index_f32(
+            _lib.ptr(spatial_shapes), _lib.ptr(sampling_loc.contiguous().float()), B, M, L, Lq, P, _lib.ptr(h),
+            _lib.ptr(w), _lib.ptr(mk), _lib.current_stream(dev)), "vllm_msda_sample_index_f32")
+    return h, w, mk
+
+
+class MSDeformAttnFunction(Function):
+    """ms_deform_attn_func.py:21-38 / modeling_ov_grounding_dino_mask_dn.py:134-180."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attw = ctx.saved_tensors
+        gv, gl, gw = ms_deform_attn_backward(value, shapes, lsi, loc, attw, grad_output, ctx.im2col_step)
+        return gv, None, None, gl, gw, None
+
+
+MultiScaleDeformableAttentionFunction = MSDeformAttnFunction  # HF name
+
+
+class MultiScaleDeformableAttnFunction(Function):
+    """mmcv flavour (multi_scale_deform_attn.py:23-97): inputs are cast to float32 (``custom_fwd``)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        if value.dtype != torch.float64:
+            value, sampling_locations, attention_weights = (value.float(), sampling_locations.float(),
+                                                             attention_weights.float())
+        output = ms_deform_attn_forward(value.contiguous(), value_spatial_shapes, value_level_start_index,
+                                        sampling_locations.contiguous(), attention_weights.contiguous(), im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attw = ctx.saved_tensors
+        gv = torch.zeros_like(value)
+        gl = torch.zeros_like(loc)
+        gw = torch.zeros_like(attw)
+        ms_deform_attn_backward_(value.contiguous(), shapes, lsi, loc.contiguous(), attw.contiguous(),
+                                 grad_output.to(value.dtype).contiguous(), gv, gl, gw, ctx.im2col_step)
+        dv, dl, dw = ctx.in_dtypes
+        return gv.to(dv), None, None, gl.to(dl), gw.to(dw), None
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+def _init_msda_parameters(mod, n_heads, n_levels, n_points):
+    """Shared initialisation (ms_deform_attn.py:66-81 == multi_scale_deform_attn.py:238-257)."""
+    nn.init.constant_(mod.sampling_offsets.weight.data, 0.0)
+    thetas = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+    grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(n_heads, 1, 1, 2).repeat(
+        1, n_levels, n_points, 1)
+    for i in range(n_points):
+        grid_init[:, :, i, :] *= i + 1
+    with torch.no_grad():
+        mod.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+    nn.init.constant_(mod.attention_weights.weight.data, 0.0)
+    nn.init.constant_(mod.attention_weights.bias.data, 0.0)
+    nn.init.xavier_uniform_(mod.value_proj.weight.data)
+    nn.init.constant_(mod.value_proj.bias.data, 0.0)
+    nn.init.xavier_uniform_(mod.output_proj.weight.data)
+    nn.init.constant_(mod.output_proj.bias.data, 0.0)
+
+
+def _sampling_locations(reference_points, sampling_offsets, spatial_shapes, n_points, use_4d_normalizer=False):
+    if reference_points.shape[-1] == 2:
+        offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        return reference_points[:, :, None, :, None, :] + \
+            sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+    if reference_points.shape[-1] == 4:
+        if use_4d_normalizer:
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            return reference_points[:, :, None, :, None, :2] + \
+                sampling_offsets / offset_normalizer[None, None, None, :, None, :] * \
+                reference_points[:, :, None, :, None, 2:] * 0.5
+        return reference_points[:, :, None, :, None, :2] + \
+            sampling_offsets / n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+    raise ValueError(
+        "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
+
+
+def _msda_apply_fp32(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
+    """The reference upcasts to fp32 around the op (ms_deform_attn.py:131-139; ...mask_dn.py:764-766)."""
+    dtype = value.dtype
+    if dtype not in (torch.float32, torch.float64):
+        out = MSDeformAttnFunction.apply(value.to(torch.float32).contiguous(), spatial_shapes, level_start_index,
+                                         sampling_locations.to(torch.float32).contiguous(),
+                                         attention_weights.to(torch.float32).contiguous(), im2col_step)
+        return out.to(dtype)
+    return MSDeformAttnFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
+                                      sampling_locations.to(dtype).contiguous(),
+                                      attention_weights.to(dtype).contiguous(), im2col_step)
+
+
+class MSDeformAttn(nn.Module):
+    """UniPose / Deformable-DETR module (unipose/ops/modules/ms_deform_attn.py:34-145)."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, use_4D_normalizer=False):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("You'd better set d_model in MSDeformAttn to make the dimension of each attention head a "
+                          "power of 2 which is more efficient in our HIP implementation (16-byte lane gathers).")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.use_4D_normalizer = use_4D_normalizer
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        _init_msda_parameters(self, self.n_heads, self.n_levels, self.n_points)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if self.sampling_offsets.bias.dtype != query.dtype:
+            self.sampling_offsets.bias.data = self.sampling_offsets.bias.data.to(query.dtype)
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels,
+                                                                  self.n_points)
+        sampling_locations = _sampling_locations(reference_points, sampling_offsets, input_spatial_shapes,
+                                                 self.n_points, self.use_4D_normalizer)
+        output = _msda_apply_fp32(value, input_spatial_shapes, input_level_start_index, sampling_locations,
+                                  attention_weights, self.im2col_step)
+        return self.output_proj(output)
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """mmcv module (mmcv/ops/multi_scale_deform_attn.py:162-367): (num_query, bs, C) unless batch_first, residual
+    ``identity`` and dropout on the output."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}")
+        if not _is_power_of_2(embed_dims // num_heads):
+            warnings.warn("You'd better set embed_dims in MultiScaleDeformAttention to make the dimension of each "
+                          "attention head a power of 2 which is more efficient in our HIP implementation.")
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims, self.num_levels, self.num_heads, self.num_points = embed_dims, num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        _init_msda_parameters(self, self.num_heads, self.num_levels, self.num_points)
+        self._is_init = True
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == num_value
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        sampling_offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels,
+                                                             self.num_points, 2)
+        attention_weights = self.attention_weights(query).view(bs, num_query, self.num_heads,
+                                                               self.num_levels * self.num_points)
+        attention_weights = attention_weights.softmax(-1).view(bs, num_query, self.num_heads, self.num_levels,
+                                                               self.num_points)
+        sampling_locations = _sampling_locations(reference_points, sampling_offsets, spatial_shapes, self.num_points)
+        output = MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                                        attention_weights, self.im2col_step).to(value.dtype)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+
+class GroundingDinoMultiscaleDeformableAttention(nn.Module):
+    """HF / Grounding-DINO module (modeling_ov_grounding_dino_mask_dn.py:646-784).  ``config`` needs ``d_model``,
+    ``num_feature_levels`` and (ignored here) ``disable_custom_kernels``."""
+
+    def __init__(self, config, num_heads: int, n_points: int):
+        super().__init__()
+        if config.d_model % num_heads != 0:
+            raise ValueError(
+                f"embed_dim (d_model) must be divisible by num_heads, but got {config.d_model} and {num_heads}")
+        dim_per_head = config.d_model // num_heads
+        if not ((dim_per_head & (dim_per_head - 1) == 0) and dim_per_head != 0):
+            warnings.warn("You'd better set embed_dim (d_model) in GroundingDinoMultiscaleDeformableAttention to make "
+                          "the dimension of each attention head a power of 2 (16-byte lane gathers in the HIP kernel).")
+        self.im2col_step = 64
+        self.d_model = config.d_model
+        self.n_levels = config.num_feature_levels
+        self.n_heads = num_heads
+        self.n_points = n_points
+        self.sampling_offsets = nn.Linear(config.d_model, num_heads * self.n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(config.d_model, num_heads * self.n_levels * n_points)
+        self.value_proj = nn.Linear(config.d_model, config.d_model)
+        self.output_proj = nn.Linear(config.d_model, config.d_model)
+        self.disable_custom_kernels = getattr(config, "disable_custom_kernels", False)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        _init_msda_parameters(self, self.n_heads, self.n_levels, self.n_points)
+
+    def with_pos_embed(self, tensor, position_embeddings):
+        return tensor if position_embeddings is None else tensor + position_embeddings
+
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                position_embeddings=None, reference_points=None, spatial_shapes=None, level_start_index=None,
+                output_attentions: bool = False):
+        if position_embeddings is not None:
+            hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
+        batch_size, num_queries, _ = hidden_states.shape
+        batch_size, sequence_length, _ = encoder_hidden_states.shape
+        if (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() != sequence_length:
+            raise ValueError(
+                "Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
+        value = self.value_proj(encoder_hidden_states)
+        if attention_mask is not None:
+            value = value.masked_fill(~attention_mask[..., None], float(0))
+        value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
+        if self.sampling_offsets.bias.dtype != hidden_states.dtype:
+            self.sampling_offsets.bias.data = self.sampling_offsets.bias.data.to(hidden_states.dtype)
+        sampling_offsets = self.sampling_offsets(hidden_states).view(batch_size, num_queries, self.n_heads,
+                                                                      self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(hidden_states).view(batch_size, num_queries, self.n_heads,
+                                                                        self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(batch_size, num_queries, self.n_heads,
+                                                                  self.n_levels, self.n_points)
+        sampling_locations = _sampling_locations(reference_points, sampling_offsets, spatial_shapes, self.n_points)
+        output = _msda_apply_fp32(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                                  self.im2col_step)
+        output = output.to(self.output_proj.weight.dtype)
+        output = self.output_proj(output)
+        return output, attention_weights
