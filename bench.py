@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: images/sec of the image -> visual-token path + MSDA forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic input PER RANK (weak scaling):
+  workload "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4" (BASELINE.json metric; configs[1] arch + configs[3] shapes)
+    * 8 images of 1336x1336 -> dynamic_preprocess gives 5 tiles of 336x336 each (mm_utils.py:39-77) = 40 tiles
+    * CLIP ViT-L/14-336 (24 layers, bf16, all 25 hidden states materialised, as the reference requests them)
+    * hidden_states[-2][:, 1:] -> mlp2x_gelu vl_bridge (1024 -> 4096 -> 4096)   => visual tokens [40, 576, 4096]
+    * N>1: RCCL all-gather of the visual tokens over xGMI
+    * MSDA forward, Grounding-DINO det head at the 1344x1344 padded image: 4 levels 168^2..21^2, M=8, D=32, P=4,
+      B=8: 6 encoder-shaped calls (Lq = S = 37485) + 6 decoder-shaped calls (Lq = 900), fp32 (the reference upcasts).
+Weights are random-init (no network), inputs synthetic and resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0): metric/value/unit + "roofline" (dominant kernel) + "rooflines" (the three kernels the
+north star names) + "cpu_baseline" (the oracle timed on the host cores, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+IMAGES_PER_RANK = 8
+TILES_PER_IMAGE = 5
+VIT = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=24, image_size=336,
+           patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+LLM_HIDDEN = 4096
+MSDA = dict(M=8, D=32, P=4, shapes=[(168, 168), (84, 84), (42, 42), (21, 21)], dec_queries=900, enc_layers=6,
+            dec_layers=6)
+
+
+def build_model(dev):
+    from transformers import CLIPVisionConfig
+    from visionllm_amd.bridge import build_vl_bridge
+    from visionllm_amd.clip_vit import CLIPVisionModel
+    torch.manual_seed(0)
+    enc = CLIPVisionModel(CLIPVisionConfig(**VIT))
+    with torch.no_grad():
+        for name, p in enc.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0, 0.02)
+    torch.manual_seed(1)
+    bridge = build_vl_bridge("mlp2x_gelu", VIT["hidden_size"], LLM_HIDDEN, use_pixelshuffle=False)
+    return enc.to(dev).to(torch.bfloat16).eval(), bridge.to(dev).to(torch.bfloat16).eval()
+
+
+def build_msda_inputs(dev, B, seed):
+    from msda_inputs import make_inputs
+    g_enc = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], mode="encoder_like", seed=seed)
+    g_dec = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], Lq=MSDA["dec_queries"], mode="encoder_like",
+                        seed=seed + 1)
+    out = {}
+    for tag, g in (("enc", g_enc), ("dec", g_dec)):
+        t = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        for k in ("value", "loc", "attw"):
+            t[k] = t[k].repeat(B, *([1] * (t[k].dim() - 1))).contiguous()
+        t["value"] = t["value"] + 0.05 * torch.randn(t["value"].shape, device=dev, generator=gen)
+        t["loc"] = (t["loc"] + 0.002 * torch.randn(t["loc"].shape, device=dev, generator=gen)).contiguous()
+        out[tag] = t
+    return out
+
+
+def msda_bytes(t):
+    B, S, M, D = t["value"].shape
+    Lq, L, P = t["loc"].shape[1], t["loc"].shape[3], t["loc"].shape[4]
+    return 4 * (B * S * M * D + B * Lq * M * L * P * 2 + B * Lq * M * L * P + B * Lq * M * D)
+
+
+def event_time(fn, iters, stream=None):
+    """Average duration (s) of fn() launched `iters` times on the CURRENT torch stream, HIP events."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
+    """Per-kernel achieved vs peak for the three kernels the north star names, each launched alone."""
+    from visionllm_amd import _lib
+    from visionllm_amd import ms_deform_attn as A
+    L = _lib.lib()
+    st = _lib.current_stream(torch.device(dev))
+    C, H, I = VIT["hidden_size"], VIT["num_attention_heads"], VIT["intermediate_size"]
+    S = (VIT["image_size"] // VIT["patch_size"]) ** 2 + 1
+    D = C // H
+    M = n_tiles * S
+    out = {}
+    # (1) MSDA encoder-shaped call: HBM bound, algorithmic bytes = value + loc + attw + out
+    t = msda_in["enc"]
+    f = lambda: A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)  # noqa: E731
+    f(); torch.cuda.synchronize()
+    sec = event_time(f, iters)
+    ab = msda_bytes(t)
+    out["msda"] = dict(kernel="msda_fwd_vec_kernel<fp32,D32,P4>", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
+                       unit="GB/s", frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6,
+                       algorithmic_bytes=ab)
+    # (2) attention kernel: MFMA bound, flops = 4*H*S^2*d per tile
+    qkv = torch.randn(n_tiles, S, 3, H, D, device=dev).to(torch.bfloat16)
+    ao = torch.empty(n_tiles, S, H, D, dtype=torch.bfloat16, device=dev)
+    f = lambda: _lib.check(L.vllm_attn_fwd_qkvpacked_bf16(_lib.ptr(qkv), _lib.ptr(ao), n_tiles, S, H, D, D ** -0.5, st))  # noqa: E731
+    f(); torch.cuda.synchronize()
+    sec = event_time(f, iters)
+    fl = 4.0 * H * S * S * D * n_tiles
+    out["attn"] = dict(kernel="attn_fwd_kernel<64>", bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF,
+                       unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None, us_per_launch=sec * 1e6,
+                       algorithmic_flops=fl)
+    # (3) the dominant GEMM (MLP fc1: [M,1024] x [4096,1024]^T + bias + quick_gelu)
+    x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(I, C, device=dev) * 0.02).to(torch.bfloat16)
+    b = torch.zeros(I, device=dev).to(torch.bfloat16)
+    y = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    f = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, I, C, C, C, I, 2,  # noqa: E731
+                                             None, None, 0, 0, st))
+    f(); torch.cuda.synchronize()
+    sec = event_time(f, iters)
+    fl = 2.0 * M * I * C
+    out["gemm"] = dict(kernel="gemm_bf16_kernel<quick_gelu> fc1", bound="mfma", achieved=fl / sec / 1e12,
+                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None,
+                       us_per_launch=sec * 1e6, algorithmic_flops=fl)
+    # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            tr = json.load(open(pmc))
+            for k in out:
+                if k in tr:
+                    out[k]["traffic"] = tr[k]
+        except Exception:
+            pass
+    return out
+
+
+def cpu_baseline():
+    """The reference's CPU path (restated in oracle/), bounded sample, extrapolated to images/sec."""
+    from msda_inputs import make_inputs
+    from oracle import msda as OM
+    from oracle import vit as OV
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    C, I, H = VIT["hidden_size"], VIT["intermediate_size"], VIT["num_attention_heads"]
+    S = (VIT["image_size"] // VIT["patch_size"]) ** 2 + 1
+    sd = {"embeddings.patch_embedding.weight": torch.randn(C, 3, 14, 14) * 0.02,
+          "embeddings.class_embedding": torch.randn(C) * 0.02,
+          "embeddings.position_embedding.weight": torch.randn(S, C) * 0.02,
+          "pre_layrnorm.weight": torch.ones(C), "pre_layrnorm.bias": torch.zeros(C)}
+    n_layers_sample = VIT["num_hidden_layers"]   # full depth for ONE tile (the sample is bounded by tile count)
+    for i in range(n_layers_sample):
+        p = f"encoder.layers.{i}."
+        for nm, shp in (("self_attn.q_proj", (C, C)), ("self_attn.k_proj", (C, C)), ("self_attn.v_proj", (C, C)),
+                        ("self_attn.out_proj", (C, C)), ("mlp.fc1", (I, C)), ("mlp.fc2", (C, I))):
+            sd[p + nm + ".weight"] = torch.randn(*shp) * 0.02
+            sd[p + nm + ".bias"] = torch.zeros(shp[0])
+        for nm in ("layer_norm1", "layer_norm2"):
+            sd[p + nm + ".weight"] = torch.ones(C)
+            sd[p + nm + ".bias"] = torch.zeros(C)
+    cfg = dict(VIT, num_hidden_layers=n_layers_sample)
+    x = torch.randn(1, 3, 336, 336)
+    with torch.no_grad():
+        OV.clip_vit_forward(sd, dict(cfg, num_hidden_layers=1), x)  # warm-up
+        t0 = time.perf_counter()
+        hs = OV.clip_vit_forward(sd, cfg, x)
+        t_vit_sample = time.perf_counter() - t0
+        bsd = {"0.weight": torch.randn(LLM_HIDDEN, C) * 0.02, "0.bias": torch.zeros(LLM_HIDDEN),
+               "2.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "2.bias": torch.zeros(LLM_HIDDEN)}
+        t0 = time.perf_counter()
+        OV.bridge_forward(bsd, "mlp2x_gelu", hs[-2][:, 1:])
+        t_bridge = time.perf_counter() - t0
+        g = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], mode="encoder_like", seed=0)
+        tv, tl, tw = torch.from_numpy(g["value"]), torch.from_numpy(g["loc"]), torch.from_numpy(g["attw"])
+        t0 = time.perf_counter()
+        OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw)
+        t_msda_enc = time.perf_counter() - t0
+        gd = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], Lq=MSDA["dec_queries"], mode="encoder_like", seed=1)
+        t0 = time.perf_counter()
+        OM.grid_sample_twin(torch.from_numpy(gd["value"]), gd["shapes"].tolist(), torch.from_numpy(gd["loc"]),
+                            torch.from_numpy(gd["attw"]))
+        t_msda_dec = time.perf_counter() - t0
+    t_tile = t_vit_sample * (VIT["num_hidden_layers"] / n_layers_sample) + t_bridge
+    t_image = TILES_PER_IMAGE * t_tile + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
+    return dict(value=1.0 / t_image, unit="images/sec", cores=threads, kind="port",
+                sample=(f"torch fp32 oracle on {threads} threads: ViT-L/14-336 1 tile x {n_layers_sample}/24 layers "
+                        f"({t_vit_sample:.2f}s) + mlp2x_gelu bridge 1 tile "
+                        f"({t_bridge:.2f}s) + reference grid_sample MSDA twin B=1 Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 "
+                        f"({t_msda_dec:.2f}s); image = 5 tiles + 6 enc + 6 dec MSDA calls (B=1 each), extrapolated from this one-tile / one-call sample"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from visionllm_amd import ms_deform_attn as A
+    from visionllm_amd.dist import all_gather_visual_tokens
+
+    enc, bridge = build_model(dev)
+    n_tiles = IMAGES_PER_RANK * TILES_PER_IMAGE
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    pixels = torch.randn(n_tiles, 3, VIT["image_size"], VIT["image_size"], device=dev, generator=gen).to(torch.bfloat16)
+    msda_in = build_msda_inputs(dev, IMAGES_PER_RANK, 200 + rank)
+
+    def step():
+        out = enc(pixels, output_hidden_states=True)
+        tokens = bridge.project_hidden_state(out.hidden_states[-2], False)
+        gathered, _ = all_gather_visual_tokens(tokens)
+        res = [gathered]
+        for tag, n in (("enc", MSDA["enc_layers"]), ("dec", MSDA["dec_layers"])):
+            t = msda_in[tag]
+            for _ in range(n):
+                res.append(A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64))
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        rl = kernel_rooflines(dev, enc, msda_in, n_tiles)
+        # dominant kernel by time share of a step: the GEMM family (~85 % of the ViT FLOPs)
+        line = {
+            "metric": "images/sec (ViT-L+projector+MSDeformAttn fwd, 1336px)",
+            "value": world * IMAGES_PER_RANK * args.steps / dt,
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4", "images_per_gpu": IMAGES_PER_RANK,
+                       "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336", "vit": "ViT-L/14-336 24L bf16",
+                       "bridge": "mlp2x_gelu 1024->4096->4096", "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
+                       "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else "")},
+            "roofline": {k: rl["gemm"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": rl["gemm"]["kernel"]},
+            "rooflines": rl,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

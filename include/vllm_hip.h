@@ -87,6 +87,133 @@ int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int
                            int B, int S, int M, int D, int L, int Lq, int P,
                            double *grad_value, double *grad_loc, double *grad_attw, vllm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Building blocks of the ViT path (bf16 storage, fp32 accumulation).  Exposed individually so the parity
+ * tests can pin every kernel against the oracle, and as bring-up hooks B4/B5 of SURVEY.md section 8b.
+ * All bf16 tensors are passed as uint16_t*.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Epilogues of vllm_gemm_bf16 */
+#define VLLM_EPI_BIAS 0        /* y = x W^T + b                                   (nn.Linear) */
+#define VLLM_EPI_GELU 1        /* y = gelu_erf(x W^T + b)                         (InternMLP.fc1+act, vl_bridge GELU) */
+#define VLLM_EPI_QUICK_GELU 2  /* y = z*sigmoid(1.702 z)                          (CLIP MLP) */
+#define VLLM_EPI_RESIDUAL 3    /* y = res + (x W^T + b) * scale                   (LayerScale + residual, modeling_intern_vit.py:206-208) */
+#define VLLM_EPI_EMBED 4       /* patch embedding: rows scattered past the CLS slot, + position embedding */
+
+/* Y[M,N] = epilogue(X[M,K] @ W[N,K]^T + bias).  Replaces F.linear / nn.Conv2d-as-GEMM on the path
+ * (modeling_intern_vit.py:112,124,128,141,172-178; modeling_visionllmv2.py:162-182).
+ * K % 64 == 0, N % 4 == 0, 16-byte aligned operands.  bias/scale may be NULL.  For VLLM_EPI_EMBED `res` is the
+ * position table [P+1, N] (row stride ldr) and P the patches per image; output row of input row m is
+ * (m / P) * (P + 1) + 1 + m % P. */
+int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
+                   int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
+                   const uint16_t *scale, const uint16_t *res, int ldr, int P, vllm_stream_t stream);
+
+/* B5: InternRMSNorm / apex FusedRMSNorm (modeling_intern_vit.py:33-58): y = w * bf16(x * rsqrt(mean(x^2)+eps)).
+ * Row strides allow the in-place QK-RMSNorm over the q / k column blocks of the qkv buffer (:131-134). */
+int vllm_rmsnorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, uint16_t *y, int ldy,
+                      long rows, int C, float eps, vllm_stream_t stream);
+/* nn.LayerNorm (CLIP pre_layrnorm / layer_norm1,2; vl_bridge LayerNorm, modeling_visionllmv2.py:166-167). */
+int vllm_layernorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, const uint16_t *bias,
+                        uint16_t *y, int ldy, long rows, int C, float eps, vllm_stream_t stream);
+
+/* B4: FlashAttention.forward(qkv[B,S,3,H,D]) -> out[B,S,H,D], non-causal, no mask, dropout 0
+ * (visionllmv2/model/internvit/flash_attention.py:30-75).  D in {64,128}. */
+int vllm_attn_fwd_qkvpacked_bf16(const uint16_t *qkv, uint16_t *out, int B, int S, int H, int D,
+                                 float softmax_scale, vllm_stream_t stream);
+
+/* Patch gather for the embedding GEMM: pixels [N,3,img,img] (bf16, or fp32 when pixel_is_f32) ->
+ * A [N*(img/patch)^2, Kpad] bf16, k = c*patch^2 + ky*patch + kx, zero padded to Kpad. */
+int vllm_im2col_patches(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int img, int patch,
+                        int Kpad, vllm_stream_t stream);
+
+/* pixel_shuffle(scale 0.5) of modeling_visionllmv2.py:381-392 applied to hidden[:, tok0:]:
+ * hidden [N, tok0+hw*hw, C] (tile stride / row stride in elements, tok0 = 1 skips CLS) -> out [N, (hw/2)^2, 4C]. */
+int vllm_pixel_shuffle_bf16(const uint16_t *hidden, long tile_stride, int ld, int tok0, uint16_t *out,
+                            int N, int hw, int C, vllm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B1. Vision encoder (the `vis_encoder` slot): one call runs patch-embed + all layers.
+ *
+ * Replaces InternVisionModel.forward (modeling_intern_vit.py:305-343: embeddings :82-90, encoder loop
+ * :253-270, layer :198-210) and transformers.CLIPVisionModel.forward (call sites
+ * visionllmv2/model/modeling_visionllmv2.py:135, 565-568).
+ * ------------------------------------------------------------------------------------------------ */
+#define VLLM_ARCH_INTERNVIT 0
+#define VLLM_ARCH_CLIP 1
+
+typedef struct VllmVitLayer {
+    const uint16_t *norm1_w, *norm1_b;   /* RMSNorm weight (InternViT, b NULL) / LayerNorm weight+bias (CLIP) */
+    const uint16_t *qkv_w, *qkv_b;       /* [3C, C] fused (CLIP: q,k,v projections concatenated), bias may be NULL */
+    const uint16_t *q_norm_w, *k_norm_w; /* QK-RMSNorm weights [C] or NULL */
+    const uint16_t *proj_w, *proj_b;     /* [C, C], [C] */
+    const uint16_t *ls1;                 /* LayerScale [C] or NULL */
+    const uint16_t *norm2_w, *norm2_b;
+    const uint16_t *fc1_w, *fc1_b;       /* [I, C], [I] */
+    const uint16_t *fc2_w, *fc2_b;       /* [C, I], [C] */
+    const uint16_t *ls2;
+} VllmVitLayer;
+
+typedef struct VllmVitDesc {
+    int arch;            /* VLLM_ARCH_* */
+    int num_layers;      /* layers to run (<= model depth; hidden_states has num_layers+1 entries) */
+    int hidden;          /* C */
+    int heads;           /* H (C/H in {64,128}) */
+    int inter;           /* I */
+    int patch;           /* 14 */
+    int image;           /* 336 / 448 */
+    int kpad;            /* padded K of the patch-embedding GEMM (multiple of 64, >= 3*patch^2) */
+    int act;             /* VLLM_EPI_GELU or VLLM_EPI_QUICK_GELU */
+    int pixel_is_f32;    /* pixel_values dtype: 0 bf16, 1 fp32 */
+    float eps;
+    const uint16_t *patch_w;   /* [C, kpad] (Conv2d weight flattened, zero padded) */
+    const uint16_t *patch_b;   /* [C] or NULL (CLIP) */
+    const uint16_t *cls;       /* [C] */
+    const uint16_t *pos;       /* [1+P, C] */
+    const uint16_t *pre_ln_w, *pre_ln_b;  /* CLIP pre_layrnorm or NULL */
+    const VllmVitLayer *layers;           /* HOST array [num_layers] of device pointers */
+} VllmVitDesc;
+
+int vllm_vit_desc_sizeof(void);   /* sizeof(VllmVitDesc): lets the ctypes mirror verify its layout */
+int vllm_vit_layer_sizeof(void);
+/* Workspace bytes needed by vllm_vit_forward for n_tiles tiles. */
+long vllm_vit_workspace_bytes(const VllmVitDesc *desc, int n_tiles);
+/* pixels [n_tiles,3,image,image]; hidden_states: HOST array of num_layers+1 DEVICE pointers, each
+ * [n_tiles, 1+P, C] bf16 contiguous (entry i = input of layer i, last = final output, exactly the tuple
+ * InternVisionEncoder returns with output_hidden_states=True).  Entries may be NULL except the last: the
+ * library then keeps that state in its workspace (nobody reads it). */
+int vllm_vit_forward(const VllmVitDesc *desc, const void *pixels, int n_tiles,
+                     uint16_t *const *hidden_states, void *workspace, long workspace_bytes,
+                     vllm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B2. Projector ("vl_bridge") with the hidden-state select / CLS drop / pixel-shuffle in front of it
+ * (modeling_visionllmv2.py:569-579, 162-182, 381-392).
+ * ------------------------------------------------------------------------------------------------ */
+#define VLLM_BRIDGE_LINEAR 0        /* nn.Linear */
+#define VLLM_BRIDGE_MLP_GELU 1      /* mlp{N}x_gelu: Linear (GELU Linear)*(depth-1) */
+#define VLLM_BRIDGE_INTERNVL_MLP 2  /* LayerNorm, Linear, GELU, Linear */
+
+typedef struct VllmBridgeDesc {
+    int kind;             /* VLLM_BRIDGE_* */
+    int depth;            /* number of Linear layers (1 for linear, N for mlpNx_gelu, 2 for internvl_mlp) */
+    int in_features;      /* C or 4C */
+    int out_features;     /* LLM hidden size */
+    int pixel_shuffle;    /* 1: apply pixel_shuffle(0.5) to the token grid first */
+    int skip_cls;         /* 1: `hidden` is [n, 1+T, C] and row 0 of every tile (CLS) is skipped (:571); 0: [n, T, C] */
+    float ln_eps;
+    const uint16_t *ln_w, *ln_b;     /* internvl_mlp LayerNorm or NULL */
+    const uint16_t *w[4], *b[4];     /* Linear weights [out,in] / biases */
+} VllmBridgeDesc;
+
+int vllm_bridge_desc_sizeof(void);
+long vllm_bridge_workspace_bytes(const VllmBridgeDesc *desc, int n_tiles, int tokens_per_tile_in);
+/* hidden: the selected hidden state [n_tiles, skip_cls+T, C] bf16; out
+ * [n_tiles, T or T/4, out_features] bf16 -- row-major [tile, token, C_llm], the layout the token splice
+ * (modeling_visionllmv2.py:582-605) consumes. */
+int vllm_bridge_forward(const VllmBridgeDesc *desc, const uint16_t *hidden, int n_tiles, int T, int C,
+                        uint16_t *out, void *workspace, long workspace_bytes, vllm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

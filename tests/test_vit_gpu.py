@@ -1,0 +1,301 @@
+"""GPU parity tests of the ViT path (every kernel through the C ABI, then the assembled encoders / bridge).
+
+Tolerances: the path computes in bf16 storage / fp32 accumulation.  Single kernels are compared with an fp32
+torch reference fed the SAME bf16-rounded inputs: the only difference is the final rounding to bf16 (2^-8
+relative) plus accumulation order, so |err| <= 1e-2 * scale.  Assembled encoders are compared with the fp32 oracle
+(oracle/vit.py, pinned to the reference classes) and must be no worse than ~2x the error the oracle itself makes
+when it is run in bf16 (i.e. what the reference's own bf16 path would give)."""
+import ast
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden_sd, load_golden
+from oracle import vit as V
+from visionllm_amd import _lib
+from visionllm_amd.bridge import build_vl_bridge, pixel_shuffle
+from visionllm_amd.clip_vit import CLIPVisionModel
+from visionllm_amd.intern_vit import InternVisionConfig, InternVisionModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def P(t):
+    return _lib.ptr(t)
+
+
+def stream():
+    return _lib.current_stream(torch.device(DEV))
+
+
+def close(out, ref, tol=1e-2, what=""):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (out - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (577, 1024, 1024), (1000, 3200, 192), (77, 64, 640),
+                                   (2 * 577, 4096, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(M, N, K, epi):
+    torch.manual_seed(M + N + K + epi)
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    ls = bf(0.1 + 0.05 * torch.randn(N, device=DEV))
+    res = bf(torch.randn(M, N, device=DEV))
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi, P(ls) if epi == 3 else None,
+                                         P(res) if epi == 3 else None, N, 0, stream()))
+    z = x.float() @ w.float().t() + b.float()
+    if epi == 1:
+        z = V.gelu_erf(z)
+    elif epi == 2:
+        z = V.quick_gelu(z)
+    elif epi == 3:
+        z = res.float() + z * ls.float()
+    close(y, z, 1e-2, f"gemm epi {epi}")
+
+
+def test_gemm_transpose_detecting():
+    """A = I-like and asymmetric B (cdna guide G9): catches swapped operands / transposed stores."""
+    M = N = K = 128
+    x = torch.zeros(M, K, device=DEV)
+    x[torch.arange(M), torch.arange(K)] = 1.0
+    w = torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 / 251.0
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().vllm_gemm_bf16(P(bf(x)), P(bf(w)), None, P(y), M, N, K, K, K, N, 0, None, None, 0, 0, stream()))
+    close(y, bf(w).float().t(), 1e-2, "identity x asymmetric W")
+
+
+def test_gemm_rejects_bad_shapes():
+    x = bf(torch.zeros(4, 100, device=DEV))
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(x), None, P(x), 4, 4, 100, 100, 100, 4, 0, None, None, 0, 0, stream()))
+
+
+@pytest.mark.parametrize("C", [64, 1024, 3200, 4096, 12800])
+def test_norms(C):
+    torch.manual_seed(C)
+    rows = 37
+    x = bf(torch.randn(rows, C, device=DEV) * 2 + 0.3)
+    w = bf(1 + 0.2 * torch.randn(C, device=DEV))
+    b = bf(0.1 * torch.randn(C, device=DEV))
+    y = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.vllm_rmsnorm_bf16(P(x), C, P(w), P(y), C, rows, C, 1e-6, stream()))
+    ref = V.rms_norm(x.cpu(), w.cpu(), 1e-6)  # the reference's own bf16 semantics (cast, then * weight)
+    close(y, ref, 8e-3, "rmsnorm")
+    _lib.check(L.vllm_layernorm_bf16(P(x), C, P(w), P(b), P(y), C, rows, C, 1e-5, stream()))
+    ref = F.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-5)
+    close(y, ref, 8e-3, "layernorm")
+
+
+def test_qk_rmsnorm_inplace_on_strided_qkv():
+    C, rows = 256, 50
+    qkv = bf(torch.randn(rows, 3 * C, device=DEV))
+    orig = qkv.clone()
+    w = bf(1 + 0.2 * torch.randn(C, device=DEV))
+    _lib.check(_lib.lib().vllm_rmsnorm_bf16(_lib.ctypes.c_void_p(qkv.data_ptr() + 2 * C), 3 * C, P(w),
+                                            _lib.ctypes.c_void_p(qkv.data_ptr() + 2 * C), 3 * C, rows, C, 1e-6, stream()))
+    ref = V.rms_norm(orig[:, C:2 * C].cpu(), w.cpu(), 1e-6)
+    close(qkv[:, C:2 * C], ref, 8e-3, "k rmsnorm")
+    assert torch.equal(qkv[:, :C], orig[:, :C]) and torch.equal(qkv[:, 2 * C:], orig[:, 2 * C:])
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, H, D, scale):
+    B, S = qkv.shape[:2]
+    q, k, v = qkv.float().reshape(B, S, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)
+    return V.attention_core(q, k, v, scale).reshape(B, S, H, D)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("S", [1, 5, 63, 64, 65, 128, 129, 577, 1025])
+def test_attention_vs_oracle(D, S):
+    torch.manual_seed(S * 3 + D)
+    B, H = 2, 3
+    qkv = bf(torch.randn(B, S, 3, H, D, device=DEV))
+    out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))
+    close(out, _attn_ref(qkv.cpu(), H, D, D ** -0.5), 1e-2, f"attention D={D} S={S}")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_attention_online_softmax_rescale_branch(D):
+    """cdna guide rule 26: force the running max to jump at a late tile (spiked key) and at the first tile."""
+    torch.manual_seed(7)
+    B, H, S = 1, 2, 300
+    qkv = torch.randn(B, S, 3, H, D, device=DEV) * 0.5
+    qkv[0, 200, 1, 0] = qkv[0, 10, 0, 0] * 8.0      # key 200 aligned with query 10 -> huge score in tile 3
+    qkv[0, 3, 1, 1] = qkv[0, 150, 0, 1] * 8.0        # key 3 dominates from the first tile on
+    qkv = bf(qkv)
+    out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))
+    ref = _attn_ref(qkv.cpu(), H, D, D ** -0.5)
+    assert torch.isfinite(out.float()).all()
+    close(out, ref, 1.5e-2, "attention with spiked keys")
+
+
+def test_attention_rejects_head_dim():
+    qkv = bf(torch.zeros(1, 4, 3, 2, 32, device=DEV))
+    out = torch.empty(1, 4, 2, 32, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), 1, 4, 2, 32, 1.0, stream()))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_im2col_and_pixel_shuffle_are_exact():
+    torch.manual_seed(0)
+    n, img, ps = 3, 56, 14
+    px = bf(torch.randn(n, 3, img, img, device=DEV))
+    kpad = 640
+    A = torch.empty(n * 16, kpad, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().vllm_im2col_patches(P(px), 0, P(A), n, img, ps, kpad, stream()))
+    ref = F.unfold(px.float(), kernel_size=ps, stride=ps).transpose(1, 2).reshape(n * 16, 588)
+    assert torch.equal(A[:, :588].float(), ref) and (A[:, 588:] == 0).all()
+    pxf = px.float()
+    _lib.check(_lib.lib().vllm_im2col_patches(P(pxf), 1, P(A), n, img, ps, kpad, stream()))
+    assert torch.equal(A[:, :588].float(), ref)
+    x = bf(torch.randn(2, 8, 8, 16, device=DEV))
+    assert torch.equal(pixel_shuffle(x).cpu(), V.pixel_shuffle(x.cpu(), 0.5))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _cfg(g):
+    return ast.literal_eval(str(g["cfg"]))
+
+
+def _oracle_errors(fwd, sd, cfg, x):
+    """fp32 oracle on bf16-rounded params/inputs, and the same oracle run in bf16 (the reference's own precision)."""
+    sd32 = {k: bf(v).float() for k, v in sd.items()}
+    ref = fwd(sd32, cfg, bf(x).float())
+    sdb = {k: bf(v) for k, v in sd.items()}
+    lo = fwd(sdb, cfg, bf(x))
+    return ref, lo
+
+
+def _check_states(states, ref, lo, what):
+    for i, (s, r, l) in enumerate(zip(states, ref, lo)):
+        scale = r.abs().max().item()
+        e_ours = (s.float().cpu() - r).abs().max().item()
+        e_bf16 = (l.float() - r).abs().max().item()
+        rms = ((s.float().cpu() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+        assert e_ours <= max(2.0 * e_bf16, 1e-2 * scale), f"{what} hs[{i}]: ours {e_ours:.4g}, bf16-oracle {e_bf16:.4g}, scale {scale:.4g}"
+        assert rms <= 1e-2, f"{what} hs[{i}]: relative rms {rms:.4g}"
+
+
+def test_intern_vit_small_vs_reference_golden():
+    g = load_golden("internvit_small_d64.npz")
+    cfgd = _cfg(g)
+    sd = golden_sd(g)
+    x = torch.from_numpy(g["pixel_values"])
+    model = InternVisionModel(InternVisionConfig(**cfgd))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).to(torch.bfloat16)
+    out = model(bf(x).to(DEV), output_hidden_states=True, return_dict=True)
+    assert len(out.hidden_states) == cfgd["num_hidden_layers"] + 1
+    ref, lo = _oracle_errors(V.intern_vit_forward, sd, cfgd, x)
+    _check_states(out.hidden_states, ref, lo, "internvit_small")
+    # and against the fixture the reference class itself produced (fp32 weights): bf16-level agreement
+    close(out.hidden_states[-1], torch.from_numpy(g["hidden_states"][-1]), 3e-2, "vs reference fp32 fixture")
+    assert torch.equal(out.last_hidden_state, out.hidden_states[-1])
+    assert torch.equal(out.pooler_output, out.last_hidden_state[:, 0, :])
+    # fp32 pixels take the in-kernel conversion path; hidden-state subset keeps only what the caller reads
+    model.keep_hidden_states = (-1, -2, -3)
+    out2 = model(bf(x).float().to(DEV), output_hidden_states=True)
+    assert out2.hidden_states[0] is None and torch.equal(out2.hidden_states[-2], out.hidden_states[-2])
+
+
+def test_clip_small_vs_reference_golden():
+    g = load_golden("clip_small_d64.npz")
+    cfgd = _cfg(g)
+    sd = golden_sd(g)
+    from transformers import CLIPVisionConfig
+    model = CLIPVisionModel(CLIPVisionConfig(**cfgd))
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys, missing.missing_keys
+    model = model.to(DEV).to(torch.bfloat16)
+    x = torch.from_numpy(g["pixel_values"])
+    out = model(pixel_values=bf(x).to(DEV), output_hidden_states=True)
+    sdp = {k: v for k, v in sd.items()}
+    ref, lo = _oracle_errors(lambda s, c, xx: V.clip_vit_forward(s, c, xx), sdp, cfgd, x)
+    _check_states(out.hidden_states, ref, lo, "clip_small")
+    close(out.hidden_states[-2], torch.from_numpy(g["hidden_states"][-2]), 3e-2, "vs HF fp32 fixture")
+
+
+def test_unsupported_head_dim_fails_loudly():
+    g = load_golden("internvit_tiny_qknorm.npz")  # head_dim 32
+    model = InternVisionModel(InternVisionConfig(**_cfg(g)))
+    model.load_state_dict(golden_sd(g))
+    model = model.to(DEV).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        model(bf(torch.from_numpy(g["pixel_values"])).to(DEV), output_hidden_states=True)
+    with pytest.raises(RuntimeError):  # fp32 parameters: refuse instead of silently casting
+        InternVisionModel(InternVisionConfig(**_cfg(load_golden("internvit_small_d64.npz")))).to(DEV)(
+            torch.zeros(1, 3, 56, 56, device=DEV))
+
+
+@pytest.mark.parametrize("arch", ["clip_l", "internvit_wide"])
+def test_real_width_encoders_vs_oracle(arch):
+    """ViT-L/14-336 width (2 layers) and InternViT-6B width (2 layers, 448 tiles): S=577 / 1025, d=64 / 128."""
+    torch.manual_seed(1)
+    if arch == "clip_l":
+        from transformers import CLIPVisionConfig
+        cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=2,
+                    image_size=336, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+        model = CLIPVisionModel(CLIPVisionConfig(**cfgd))
+        fwd = lambda s, c, xx: V.clip_vit_forward(s, c, xx, prefix="vision_model.")  # noqa: E731
+        n = 2
+    else:
+        cfgd = dict(hidden_size=3200, num_attention_heads=25, intermediate_size=12800, num_hidden_layers=2,
+                    image_size=448, patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu",
+                    layer_norm_eps=1e-6)
+        model = InternVisionModel(InternVisionConfig(**cfgd))
+        fwd = V.intern_vit_forward
+        n = 1
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2 and "embedding" not in name:
+                p.normal_(0, 0.02)
+            elif name.endswith("ls1") or name.endswith("ls2"):
+                p.fill_(0.1)
+            elif "embedding" in name:
+                p.normal_(0, 0.02)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if "position_ids" not in k}
+    x = torch.randn(n, 3, cfgd["image_size"], cfgd["image_size"])
+    model = model.to(DEV).to(torch.bfloat16)
+    out = model(bf(x).to(DEV), output_hidden_states=True)
+    ref, lo = _oracle_errors(fwd, sd, cfgd, x)
+    _check_states(out.hidden_states, ref, lo, arch)
+
+
+@pytest.mark.parametrize("kind,ps", [("linear", False), ("mlp2x_gelu", False), ("internvl_mlp", True), ("mlp2x_gelu", True)])
+def test_bridge_vs_oracle(kind, ps):
+    torch.manual_seed(3)
+    n, hw, C, Cl = 3, 8, 128, 256
+    hidden = bf(torch.randn(n, 1 + hw * hw, C))
+    br = build_vl_bridge(kind, C, Cl, use_pixelshuffle=ps)
+    with torch.no_grad():
+        for p in br.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    sd = {k: bf(v.detach()).float() for k, v in br.state_dict().items()}
+    feats = V.select_features([hidden.float(), hidden.float()], -2, ps)
+    ref = V.bridge_forward(sd, kind, feats)
+    br = br.to(DEV).to(torch.bfloat16)
+    out = br.project_hidden_state(hidden.to(DEV), ps)   # fused path: CLS skipped / shuffled in-kernel
+    close(out, ref, 1.5e-2, f"bridge {kind} fused")
+    out2 = br(feats.to(torch.bfloat16).to(DEV))          # drop-in path: the tensor the reference passes at :579
+    close(out2, ref, 1.5e-2, f"bridge {kind} drop-in")

@@ -36,9 +36,10 @@ def parse_header(path: str = HEADER):
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
-    for m in re.finditer(r"\b(int|void|const\s+char\s*\*)\s*(vllm_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|long|void|const\s+char\s*\*)\s*(vllm_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else ctypes.c_int)
+        restype = (ctypes.c_char_p if "char" in ret else None if ret == "void"
+                   else ctypes.c_long if ret == "long" else ctypes.c_int)
         argtypes = []
         if args and args != "void":
             for a in args.split(","):
@@ -89,3 +90,51 @@ def ptr(t):
 def current_stream(device=None):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---- ctypes mirrors of the descriptor structs of include/vllm_hip.h (sizes are verified against the library) ----
+_P = ctypes.c_void_p
+
+
+class VllmVitLayer(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "q_norm_w", "k_norm_w", "proj_w", "proj_b",
+                                  "ls1", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VllmVitDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("arch", "num_layers", "hidden", "heads", "inter", "patch", "image",
+                                            "kpad", "act", "pixel_is_f32")] + \
+               [("eps", ctypes.c_float)] + \
+               [(n, _P) for n in ("patch_w", "patch_b", "cls", "pos", "pre_ln_w", "pre_ln_b")] + \
+               [("layers", ctypes.POINTER(VllmVitLayer))]
+
+
+class VllmBridgeDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("kind", "depth", "in_features", "out_features", "pixel_shuffle",
+                                            "skip_cls")] + \
+               [("ln_eps", ctypes.c_float), ("ln_w", _P), ("ln_b", _P), ("w", _P * 4), ("b", _P * 4)]
+
+
+def check_struct_layouts():
+    L = lib()
+    assert ctypes.sizeof(VllmVitDesc) == L.vllm_vit_desc_sizeof(), "VllmVitDesc layout mismatch"
+    assert ctypes.sizeof(VllmVitLayer) == L.vllm_vit_layer_sizeof(), "VllmVitLayer layout mismatch"
+    assert ctypes.sizeof(VllmBridgeDesc) == L.vllm_bridge_desc_sizeof(), "VllmBridgeDesc layout mismatch"
+
+
+EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_EMBED = 0, 1, 2, 3, 4
+ARCH_INTERNVIT, ARCH_CLIP = 0, 1
+BRIDGE_LINEAR, BRIDGE_MLP_GELU, BRIDGE_INTERNVL_MLP = 0, 1, 2
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-device scratch buffer (torch owns the memory; the library never allocates)."""
+    import torch
+    key = (str(device),)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

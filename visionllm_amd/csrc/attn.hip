@@ -1,0 +1,253 @@
+// Fused (flash-style) multi-head self-attention forward for the ViT tiles, bf16 in/out, fp32 softmax/accumulate.
+//
+// Replaces  FlashAttention.forward / flash_attn_varlen_qkvpacked_func
+//             (VisionLLMv2/visionllmv2/model/internvit/flash_attention.py:30-75; causal=False, dropout 0,
+//              softmax_scale = d^-0.5) and InternAttention._naive_attn's (q*scale)@k^T -> softmax -> @v
+//             (modeling_intern_vit.py:136-140); same math for CLIP's eager attention.
+// Tiles never attend to each other, so the attention "window" is one tile: S = 577 (336^2) or 1025 (448^2).
+//
+// gfx950 design (wave64, v_mfma_f32_32x32x16_bf16):
+//   * block = 4 waves = 128 query rows of one (tile, head); each wave owns 32 query rows, Q lives in registers;
+//   * K/V tiles of 64 keys are staged by LDS-DMA (global_load_lds_dwordx4) into a 2-stage ring; the LDS image is
+//     lane-linear, so the bank swizzles are applied to the per-lane SOURCE address and undone on the read side;
+//   * scores are computed TRANSPOSED (S^T = K Q^T): each lane then holds 32 scores of ONE query row, so the
+//     softmax row reductions are in-register plus a single lane<->lane+32 exchange, and P (converted in place
+//     to bf16) already has the MFMA B-operand layout for O^T += V^T P^T -- no P round trip through LDS;
+//   * V stays row-major in LDS and is read with the hardware transpose ds_read_b64_tr_b16 (layout verified on
+//     the device by tools/probes/probe.hip);
+//   * online softmax in the exp2 domain (scale*log2(e) folded into one FMA), key tail masked in the last tile;
+//   * (tile, head) -> XCD mapping keeps all query blocks of a head on one XCD (K/V re-reads hit that L2).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vllm {
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_THREADS = 256;
+constexpr int QBLK = 128;   // query rows per block
+constexpr int KVBLK = 64;   // keys per tile
+
+template <int D> __device__ __forceinline__ int swz_k(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
+template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
+
+template <int D, bool ISV>
+__device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
+                                         int wave, int lane)
+{
+    constexpr int CPR = D / 8;           // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;        // rows per wave instruction (1 KiB)
+    constexpr int NI = KVBLK / RPI / 4;  // instructions per wave
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+        const int ii = wave * NI + s;
+        const int r = ii * RPI + lane / CPR;
+        const int p = lane % CPR;
+        const int c = p ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));
+        int grow = k0 + r;
+        grow = grow < S ? grow : S - 1;
+        const uint16_t *g = base + (long)grow * ts + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + ii * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi)
+{
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs a)
+{
+    constexpr int KS = D / 16;            // k-steps of the QK^T product
+    constexpr int DB = D / 32;            // 32-wide output blocks
+    constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K | V]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // ---- block -> (b, head, q tile): all q tiles of a (b, head) on one XCD ----
+    const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+    const int bh = (sidx / a.nqt) * 8 + xcd;
+    const int qt = sidx % a.nqt;
+    if (bh >= a.B * a.H) return;
+    const int b = bh / a.H, head = bh % a.H;
+
+    const uint16_t *qb = a.q + (long)b * a.q_bs + (long)head * a.q_hs;
+    const uint16_t *kb_ = a.k + (long)b * a.k_bs + (long)head * a.k_hs;
+    const uint16_t *vb_ = a.v + (long)b * a.v_bs + (long)head * a.v_hs;
+
+    // ---- Q fragments (B operand): lane (q = l31, hh) holds Q[q][16*ks + 8*hh .. +7] ----
+    const int q_row = qt * QBLK + wave * 32 + l31;
+    const int q_ld = q_row < a.S ? q_row : a.S - 1;
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8_t *>(qb + (long)q_ld * a.q_ts + ks * 16 + hh * 8);
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    const int nkt = (a.S + KVBLK - 1) / KVBLK;
+    stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane);
+    stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane);
+
+    for (int t = 0; t < nkt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // tile t landed for every wave; everyone is done reading the other stage
+        const char *ks_ = smem + (t & 1) * 2 * TILE;
+        const char *vs_ = ks_ + TILE;
+        if (t + 1 < nkt) {
+            char *nx = smem + ((t + 1) & 1) * 2 * TILE;
+            stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane);
+            stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane);
+        }
+
+        // ---- S^T = K Q^T : two 32-key blocks ----
+        f32x16_t st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            const int row = kb * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(
+                    ks_ + row * (D * 2) + (((2 * ks + hh) ^ swz_k<D>(row)) << 4));
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (exp2 domain); lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31 ----
+        const int k0 = t * KVBLK;
+        float mx = -1.0e30f;
+        if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float s2 = st[kb][r] * a.scale_log2e;
+                    st[kb][r] = key < a.S ? s2 : -1.0e30f;
+                    mx = fmaxf(mx, st[kb][r]);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] *= a.scale_log2e;
+                    mx = fmaxf(mx, st[kb][r]);
+                }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        uint32_t pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                const float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] - m_new);
+                psum += p0 + p1;
+                pk[kb][r >> 1] = cvt_pk_bf16(p0, p1);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11} ----
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 pw = {pk[kb][4 * u], pk[kb][4 * u + 1], pk[kb][4 * u + 2], pk[kb][4 * u + 3]};
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+                const int key1 = kb * 32 + 16 * u + 4 * hh + (i16 >> 2);
+                const int key2 = key1 + 8;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int c = d * 4 + 2 * g1 + ((i16 & 3) >> 1);
+                    const int sub = (i16 & 1) << 3;
+                    const s16x4_t v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t *)(vs_ + key1 * (D * 2) + ((c ^ swz_v<D>(key1)) << 4) + sub));
+                    const s16x4_t v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t *)(vs_ + key2 * (D * 2) + ((c ^ swz_v<D>(key2)) << 4) + sub));
+                    const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_row < a.S) {
+        uint16_t *orow = a.out + (((long)b * a.S + q_row) * a.H + head) * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2_t w;
+                w.x = pack_bf16x2(o[d][4 * rq] * inv, o[d][4 * rq + 1] * inv);
+                w.y = pack_bf16x2(o[d][4 * rq + 2] * inv, o[d][4 * rq + 3] * inv);
+                *reinterpret_cast<uint2_t *>(orow + d * 32 + 8 * rq + 4 * hh) = w;
+            }
+    }
+}
+
+int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
+{
+    VLLM_REQUIRE(a.B >= 0 && a.S > 0 && a.H > 0, "attn: bad dims B=%d S=%d H=%d", a.B, a.S, a.H);
+    VLLM_REQUIRE(D == 64 || D == 128, "attn: head_dim %d not supported (64 or 128)", D);
+    if (a.B == 0) return VLLM_OK;
+    VLLM_REQUIRE(a.q && a.k && a.v && a.out, "attn: null pointer");
+    VLLM_REQUIRE(aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0 &&
+                     a.q_ts % 8 == 0 && a.k_ts % 8 == 0 && a.v_ts % 8 == 0 && a.q_hs % 8 == 0 && a.k_hs % 8 == 0 &&
+                     a.v_hs % 8 == 0 && a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0,
+                 "attn: q/k/v must be 16-byte aligned with strides multiple of 8 elements");
+    a.nqt = (a.S + QBLK - 1) / QBLK;
+    const long groups = ((long)a.B * a.H + 7) / 8;
+    const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
+    const size_t lds = 4 * (size_t)KVBLK * D * 2;
+    if (D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, lds, st, a);
+    VLLM_CHECK_LAUNCH("attn_fwd_kernel");
+    return VLLM_OK;
+}
+
+}  // namespace vllm
+
+using namespace vllm;
+
+// B4: FlashAttention.forward(qkv[B,S,3,H,D]) -> out[B,S,H,D]   (flash_attention.py:30-75)
+extern "C" int vllm_attn_fwd_qkvpacked_bf16(const uint16_t *qkv, uint16_t *out, int B, int S, int H, int D,
+                                            float softmax_scale, vllm_stream_t stream)
+{
+    AttnArgs a;
+    const long C = (long)H * D;
+    a.q = qkv; a.k = qkv ? qkv + C : nullptr; a.v = qkv ? qkv + 2 * C : nullptr; a.out = out;
+    a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * C;
+    a.q_ts = a.k_ts = a.v_ts = (int)(3 * C);
+    a.q_hs = a.k_hs = a.v_hs = D;
+    a.B = B; a.S = S; a.H = H; a.nqt = 0;
+    a.scale_log2e = softmax_scale * 1.4426950408889634f;
+    return attn_fwd_launch(a, D, (hipStream_t)stream);
+}

@@ -1,0 +1,163 @@
+// Data-movement kernels around the ViT GEMMs (HBM-bound gathers, coalesced on the write side).
+//
+//   im2col_patches : pixels [N,3,IMG,IMG] -> A [N*P, Kpad] with k = c*ps*ps + ky*ps + kx (== Conv2d weight
+//                    flattening), zero padded to Kpad (multiple of 64) so the patch embedding runs as a GEMM.
+//                    Replaces the strided gather inside nn.Conv2d(3, C, k=s=14)
+//                    (VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:73-75, 85-86).
+//   cls_rows       : hidden[n, 0, :] = class_embedding + position_embedding[0]   (:87-89)
+//   pixel_shuffle  : [N, 1+h*w, C] (CLS dropped) -> [N, (h/2)*(w/2), 4C] with the InternVL (w,h) permute order
+//                    (visionllmv2/model/modeling_visionllmv2.py:381-392, 569-578)
+//   drop_cls       : [N, 1+T, C] -> [N, T, C]   (:571)  (only used by the stand-alone bridge entry point; the
+//                    fused path lets the projector GEMM skip the CLS rows while staging)
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vllm {
+
+// One thread per (patch, channel, ky) row segment of `ps` pixels.
+template <typename PIX>
+__global__ __launch_bounds__(256) void im2col_kernel(const PIX *__restrict__ px, uint16_t *__restrict__ A, int N,
+                                                     int img, int ps, int g /*patches per side*/, int Kpad)
+{
+    const int P = g * g;
+    const long nseg = (long)N * P * 3 * ps;
+    const int K = 3 * ps * ps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += (long)gridDim.x * blockDim.x) {
+        const int ky = (int)(i % ps);
+        long t = i / ps;
+        const int c = (int)(t % 3);
+        t /= 3;
+        const int p = (int)(t % P);
+        const int n = (int)(t / P);
+        const int pyy = p / g, pxx = p % g;
+        const PIX *src = px + (((long)n * 3 + c) * img + (pyy * ps + ky)) * img + pxx * ps;
+        uint16_t *dst = A + ((long)n * P + p) * Kpad + c * ps * ps + ky * ps;
+        for (int kx = 0; kx < ps; ++kx) {
+            if constexpr (sizeof(PIX) == 2) dst[kx] = (uint16_t)src[kx];
+            else dst[kx] = f32_to_bf16((float)src[kx]);
+        }
+        if (c == 2 && ky == ps - 1)
+            for (int k = K; k < Kpad; ++k) A[((long)n * P + p) * Kpad + k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(const uint16_t *__restrict__ cls, const uint16_t *__restrict__ pos,
+                                                       uint16_t *__restrict__ hidden, int N, int S, int C)
+{
+    const long n_el = (long)N * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long n = i / C;
+        // reference adds in the parameter dtype (bf16): one rounding of the sum
+        hidden[n * (long)S * C + c] = f32_to_bf16(bf16_to_f32(cls[c]) + bf16_to_f32(pos[c]));
+    }
+}
+
+// 16-byte chunk copy: out[n][i2*(h/2)+j2][a*2C + bs*C + ch] = in[n][1 + (2*i2+a)*h + (2*j2+bs)][ch]
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const uint16_t *__restrict__ in, long in_tile_stride,
+                                                            int ldin, int tok0, uint16_t *__restrict__ out, int N, int hw,
+                                                            int C)
+{
+    const int h2 = hw / 2, cch = C / 8;
+    const long nchunks = (long)N * h2 * h2 * 4 * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % cch);
+        long t = i / cch;
+        const int quad = (int)(t % 4);
+        t /= 4;
+        const int j2 = (int)(t % h2);
+        t /= h2;
+        const int i2 = (int)(t % h2);
+        const long n = t / h2;
+        const int a = quad >> 1, bs = quad & 1;
+        const long tok = tok0 + (long)(2 * i2 + a) * hw + (2 * j2 + bs);
+        const uint4_t v = *reinterpret_cast<const uint4_t *>(in + n * in_tile_stride + tok * ldin + ck * 8);
+        *reinterpret_cast<uint4_t *>(out + (((n * h2 + i2) * h2 + j2) * 4L + quad) * C + ck * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void drop_cls_kernel(const uint16_t *__restrict__ in, long in_tile_stride, int ldin,
+                                                       uint16_t *__restrict__ out, int N, int T, int C)
+{
+    const int cch = C / 8;
+    const long nchunks = (long)N * T * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % cch);
+        long t = i / cch;
+        const int tok = (int)(t % T);
+        const long n = t / T;
+        *reinterpret_cast<uint4_t *>(out + (n * T + tok) * (long)C + ck * 8) =
+            *reinterpret_cast<const uint4_t *>(in + n * in_tile_stride + (long)(1 + tok) * ldin + ck * 8);
+    }
+}
+
+static inline unsigned grid_for(long n)
+{
+    long b = (n + 255) / 256;
+    if (b > 256L * 16) b = 256L * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int im2col_launch(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int img, int ps, int Kpad, hipStream_t st)
+{
+    VLLM_REQUIRE(pixels && A, "im2col: null pointer");
+    VLLM_REQUIRE(ps > 0 && img % ps == 0 && Kpad >= 3 * ps * ps, "im2col: bad geometry img=%d patch=%d Kpad=%d", img, ps, Kpad);
+    if (N == 0) return VLLM_OK;
+    const int g = img / ps;
+    const long nseg = (long)N * g * g * 3 * ps;
+    if (pixel_is_f32)
+        hipLaunchKernelGGL((im2col_kernel<float>), dim3(grid_for(nseg)), dim3(256), 0, st, (const float *)pixels, A, N, img, ps, g, Kpad);
+    else
+        hipLaunchKernelGGL((im2col_kernel<uint16_t>), dim3(grid_for(nseg)), dim3(256), 0, st, (const uint16_t *)pixels, A, N, img, ps, g, Kpad);
+    VLLM_CHECK_LAUNCH("im2col_kernel");
+    return VLLM_OK;
+}
+
+int cls_rows_launch(const uint16_t *cls, const uint16_t *pos, uint16_t *hidden, int N, int S, int C, hipStream_t st)
+{
+    if (N == 0) return VLLM_OK;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((long)N * C)), dim3(256), 0, st, cls, pos, hidden, N, S, C);
+    VLLM_CHECK_LAUNCH("cls_rows_kernel");
+    return VLLM_OK;
+}
+
+int pixel_shuffle_launch(const uint16_t *in, long in_tile_stride, int ldin, int tok0, uint16_t *out, int N, int hw,
+                         int C, hipStream_t st)
+{
+    VLLM_REQUIRE(in && out, "pixel_shuffle: null pointer");
+    VLLM_REQUIRE(hw % 2 == 0 && C % 8 == 0 && ldin % 8 == 0 && in_tile_stride % 8 == 0 && aligned16(in) && aligned16(out),
+                 "pixel_shuffle: needs even grid, C %% 8 == 0 and 16-byte alignment");
+    if (N == 0) return VLLM_OK;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((long)N * hw * hw * C / 8)), dim3(256), 0, st, in,
+                       in_tile_stride, ldin, tok0, out, N, hw, C);
+    VLLM_CHECK_LAUNCH("pixel_shuffle_kernel");
+    return VLLM_OK;
+}
+
+int drop_cls_launch(const uint16_t *in, long in_tile_stride, int ldin, uint16_t *out, int N, int T, int C, hipStream_t st)
+{
+    VLLM_REQUIRE(in && out && C % 8 == 0 && ldin % 8 == 0 && in_tile_stride % 8 == 0 && aligned16(in) && aligned16(out),
+                 "drop_cls: bad arguments");
+    if (N == 0) return VLLM_OK;
+    hipLaunchKernelGGL(drop_cls_kernel, dim3(grid_for((long)N * T * C / 8)), dim3(256), 0, st, in, in_tile_stride, ldin,
+                       out, N, T, C);
+    VLLM_CHECK_LAUNCH("drop_cls_kernel");
+    return VLLM_OK;
+}
+
+}  // namespace vllm
+
+using namespace vllm;
+
+extern "C" int vllm_im2col_patches(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int img, int patch,
+                                   int Kpad, vllm_stream_t stream)
+{
+    return im2col_launch(pixels, pixel_is_f32, A, N, img, patch, Kpad, (hipStream_t)stream);
+}
+
+extern "C" int vllm_pixel_shuffle_bf16(const uint16_t *hidden, long tile_stride, int ld, int tok0, uint16_t *out, int N,
+                                       int hw, int C, vllm_stream_t stream)
+{
+    return pixel_shuffle_launch(hidden, tile_stride, ld, tok0, out, N, hw, C, (hipStream_t)stream);
+}

@@ -1,0 +1,209 @@
+// bf16 GEMM for the ViT / projector linears:  Y[M,N] = epilogue( X[M,K] @ W[N,K]^T + bias )   (nn.Linear layout)
+//
+// Replaces the rocBLAS/cuBLAS calls behind F.linear in
+//   InternAttention.qkv / proj       (VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:112, 124, 128, 141)
+//   InternMLP.fc1 / fc2 + GELU       (:172-178)
+//   LayerScale + residual            (:206-208)  -> fused into the producing GEMM's epilogue
+//   patch-embedding Conv2d (as GEMM) (:73-75, 85-89)  -> EPI_EMBED adds bias + position embedding and scatters
+//                                                        rows past the CLS slot
+//   vl_bridge Linear/GELU            (visionllmv2/model/modeling_visionllmv2.py:162-182)
+//
+// gfx950 design: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// Both operands are K-contiguous ("B^T input"), staged with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip)
+// into a double-buffered, XOR-swizzled image: LDS is lane-linear, so the swizzle is applied to the per-lane
+// SOURCE address and again on the ds_read_b128 side (16-byte chunk c of row r lives at chunk c ^ (r & 7)), which
+// makes every 16-lane ds_read_b128 group hit 16 distinct bank slots.  The MFMA operands are swapped
+// (A := W rows, B := X rows) so each lane ends up with 4 consecutive output features of one token -> packed
+// 8-byte bf16 stores and vector loads of bias / layer-scale / residual.  Tile -> block mapping is XCD-aware:
+// an XCD owns a fixed subset of W panels (they stay in its 4 MiB L2) and streams the X panels.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vllm {
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+// Stage one 128 x 64 bf16 operand tile: 16 segments of 8 rows, 4 segments per wave, one LDS-DMA per segment.
+__device__ __forceinline__ void stage_tile(const uint16_t *__restrict__ src, int ld, int row0, int nrows, int k0,
+                                           char *lds_tile, int wave, int lane, int skipP = 0)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int seg = wave * 4 + s;
+        const int r = seg * 8 + (lane >> 3);
+        const int cp = lane & 7;                 // chunk position in the LDS row
+        const int c = cp ^ (r & 7);              // source chunk that must land there
+        int grow = row0 + r;
+        grow = grow < nrows ? grow : nrows - 1;  // clamp: rows past the edge are computed but never stored
+        if (skipP > 0) grow += grow / skipP + 1;  // X is [n, 1+P, K] and the CLS row of every image is skipped
+        const uint16_t *g = src + (size_t)grow * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + seg * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][X tile | W tile]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile mapping ----
+    int tile = blockIdx.x;
+    int tm_idx, tn_idx;
+    {
+        const int xcd = tile & 7, s = tile >> 3;
+        if ((a.nt & 7) == 0) {                   // XCD x owns W panels {x, x+8, ...}
+            const int npx = a.nt >> 3;
+            tn_idx = xcd + 8 * (s % npx);
+            tm_idx = s / npx;
+        } else {                                 // generic: XCD x owns X panels {x, x+8, ...}, all W panels
+            tm_idx = xcd + 8 * (s / a.nt);
+            tn_idx = s % a.nt;
+        }
+        if (tm_idx >= a.mt || tn_idx >= a.nt) return;   // padding blocks (grid rounded up)
+    }
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+
+    f32x4_t acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / BK;
+    stage_tile(a.X, a.ldx, m0, a.M, 0, smem, wave, lane, a.xP);
+    stage_tile(a.W, a.ldw, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, kq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
+        char *nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < nk) {
+            stage_tile(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nxt, wave, lane, a.xP);
+            stage_tile(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        const char *xs = cur, *ws = cur + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t wf[4], xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rw = wn * 64 + t * 16 + fr;
+                wf[t] = *reinterpret_cast<const bf16x8_t *>(ws + rw * 128 + (((ks * 4 + kq) ^ (rw & 7)) << 4));
+                const int rx = wm * 64 + t * 16 + fr;
+                xf[t] = *reinterpret_cast<const bf16x8_t *>(xs + rx * 128 + (((ks * 4 + kq) ^ (rx & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds features n..n+3 (rows of the swapped product) of token m ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + kq * 4;
+        if (n >= a.N) continue;
+        float bia[4] = {0.f, 0.f, 0.f, 0.f}, scl[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.bias) {
+            const uint2_t b = *reinterpret_cast<const uint2_t *>(a.bias + n);
+            bia[0] = bf16lo_to_f32(b.x); bia[1] = bf16hi_to_f32(b.x); bia[2] = bf16lo_to_f32(b.y); bia[3] = bf16hi_to_f32(b.y);
+        }
+        if (EPI == EPI_RESIDUAL && a.scale) {
+            const uint2_t s = *reinterpret_cast<const uint2_t *>(a.scale + n);
+            scl[0] = bf16lo_to_f32(s.x); scl[1] = bf16hi_to_f32(s.x); scl[2] = bf16lo_to_f32(s.y); scl[3] = bf16hi_to_f32(s.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + fr;
+            if (m >= a.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bia[r];
+            size_t orow = (size_t)m;
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (EPI == EPI_QUICK_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+            } else if (EPI == EPI_RESIDUAL) {
+                const uint2_t rr = *reinterpret_cast<const uint2_t *>(a.res + (size_t)m * a.ldr + n);
+                v[0] = bf16lo_to_f32(rr.x) + v[0] * scl[0]; v[1] = bf16hi_to_f32(rr.x) + v[1] * scl[1];
+                v[2] = bf16lo_to_f32(rr.y) + v[2] * scl[2]; v[3] = bf16hi_to_f32(rr.y) + v[3] * scl[3];
+            } else if (EPI == EPI_EMBED) {
+                const int img = m / a.P, p = m - img * a.P;
+                orow = (size_t)img * (a.P + 1) + 1 + p;
+                const uint2_t pp = *reinterpret_cast<const uint2_t *>(a.res + (size_t)(1 + p) * a.ldr + n);
+                v[0] += bf16lo_to_f32(pp.x); v[1] += bf16hi_to_f32(pp.x); v[2] += bf16lo_to_f32(pp.y); v[3] += bf16hi_to_f32(pp.y);
+            }
+            uint2_t o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2_t *>(a.Y + orow * a.ldy + n) = o;
+        }
+    }
+}
+
+int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
+{
+    VLLM_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "gemm: bad dims M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.M == 0) return VLLM_OK;
+    VLLM_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+    VLLM_REQUIRE(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
+    VLLM_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0 && a.ldy % 4 == 0 && aligned16(a.X) && aligned16(a.W) &&
+                     (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0,
+                 "gemm: operands must be 16-byte aligned with row strides multiple of 8 elements");
+    VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
+    VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
+    a.mt = ceil_div(a.M, BM);
+    a.nt = ceil_div(a.N, BN);
+    long tiles;
+    if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
+    else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;   // generic mapping pads the X-panel count to 8
+    const dim3 grid((unsigned)tiles), block(GEMM_THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+#define L(E) hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, lds, st, a)
+    switch (epi) {
+    case EPI_BIAS: L(EPI_BIAS); break;
+    case EPI_GELU: L(EPI_GELU); break;
+    case EPI_QUICK_GELU: L(EPI_QUICK_GELU); break;
+    case EPI_RESIDUAL: L(EPI_RESIDUAL); break;
+    case EPI_EMBED: L(EPI_EMBED); break;
+    default: set_error("gemm: unknown epilogue %d", epi); return VLLM_EINVAL;
+    }
+#undef L
+    VLLM_CHECK_LAUNCH("gemm_bf16_kernel");
+    return VLLM_OK;
+}
+
+}  // namespace vllm
+
+using namespace vllm;
+
+extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y, int M, int N,
+                              int K, int ldx, int ldw, int ldy, int epilogue, const uint16_t *scale,
+                              const uint16_t *res, int ldr, int P, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(X && W && Y, "vllm_gemm_bf16: null pointer");
+    GemmArgs a;
+    a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0;
+    return gemm_bf16_launch(epilogue, a, (hipStream_t)stream);
+}

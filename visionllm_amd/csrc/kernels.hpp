@@ -1,0 +1,61 @@
+// Internal launch interface shared by the kernel files and the orchestrators (vit.cpp, bridge).
+#pragma once
+#include "common.hpp"
+
+namespace vllm {
+
+enum GemmEpilogue : int {
+    EPI_BIAS = VLLM_EPI_BIAS,
+    EPI_GELU = VLLM_EPI_GELU,
+    EPI_QUICK_GELU = VLLM_EPI_QUICK_GELU,
+    EPI_RESIDUAL = VLLM_EPI_RESIDUAL,
+    EPI_EMBED = VLLM_EPI_EMBED,
+};
+
+struct GemmArgs {
+    const uint16_t *X;      // [M, K] row stride ldx
+    const uint16_t *W;      // [N, K] row stride ldw
+    uint16_t *Y;            // [M', N] row stride ldy
+    const uint16_t *bias;   // [N] or null
+    const uint16_t *scale;  // [N] layer-scale (EPI_RESIDUAL) or null
+    const uint16_t *res;    // [M, N] residual, row stride ldr (EPI_RESIDUAL); [P+1, N] position table (EPI_EMBED)
+    int M, N, K;
+    int ldx, ldw, ldy, ldr;
+    int P;                  // patches per image (EPI_EMBED)
+    int mt, nt;             // tile counts (filled by the launcher)
+    int xP;                 // >0: X is [n, 1+xP, K] and row m reads X row m + m/xP + 1 (CLS rows skipped)
+};
+
+int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);
+
+inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint16_t *W, int ldw, const uint16_t *bias,
+                uint16_t *Y, int ldy, int M, int N, int K, const uint16_t *scale = nullptr, const uint16_t *res = nullptr,
+                int ldr = 0, int P = 0, int xP = 0)
+{
+    GemmArgs a;
+    a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP;
+    return gemm_bf16_launch(epi, a, st);
+}
+
+int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
+                     long rows, int C, float eps, hipStream_t st);
+
+struct AttnArgs {
+    const uint16_t *q, *k, *v;  // element pointers; D contiguous
+    uint16_t *out;              // [B, S, H, D]
+    long q_bs, k_bs, v_bs;      // batch strides (elements)
+    int q_ts, k_ts, v_ts;       // token strides
+    int q_hs, k_hs, v_hs;       // head strides
+    int B, S, H;
+    int nqt;                    // query tiles per (b, h) (filled by the launcher)
+    float scale_log2e;
+};
+int attn_fwd_launch(AttnArgs a, int D, hipStream_t st);
+
+int im2col_launch(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int img, int ps, int Kpad, hipStream_t st);
+int cls_rows_launch(const uint16_t *cls, const uint16_t *pos, uint16_t *hidden, int N, int S, int C, hipStream_t st);
+int pixel_shuffle_launch(const uint16_t *in, long in_tile_stride, int ldin, int tok0, uint16_t *out, int N, int hw,
+                         int C, hipStream_t st);
+
+}  // namespace vllm

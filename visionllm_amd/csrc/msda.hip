@@ -10,10 +10,12 @@
 // MI355X design (not a translation -- the reference runs one thread per output scalar and re-reads loc/weight
 // D times):
 //   * one LPG-lane group per (b,q,m) "pair", LPG = D/CPL lanes, each lane owning CPL = 16 B worth of channels
-//     (4 fp32 / 8 bf16): every corner gather is one coalesced 16 B/lane load, 64/LPG pairs per wave64, and the
-//     wave's output is one contiguous 1 KiB (fp32, D=32) store;
-//   * sampling locations / weights of the wave's pairs are contiguous in memory: they are loaded ONCE per wave
-//     with coalesced loads into a wave-private LDS slice and re-read as LDS broadcasts;
+//     (4 fp32 / 8 bf16): every corner gather is one coalesced 16 B/lane load; a wave64 holds 64/LPG CONSECUTIVE
+//     QUERIES OF ONE HEAD (not one query x all heads): consecutive queries sample neighbouring pixels, so the
+//     wave keeps re-touching the same 128-byte lines and the vector L1 absorbs most of the 18x gather
+//     amplification (measured: the one-query-x-8-heads mapping was bound by L2 line requests, 1040 us @ cfg 4);
+//   * sampling locations / weights of the wave's pairs (128 B per pair) are loaded ONCE per wave into a
+//     wave-private LDS slice and re-read as LDS broadcasts;
 //   * all 4*P corner loads of a level are issued unconditionally from clamped addresses (selects, not branches,
 //     decide what contributes) so the memory pipeline sees 16 independent 16 B gathers per lane per level;
 //   * level metadata (H, W, start) comes from the reference's DEVICE int64 tensors through scalar loads;
@@ -107,28 +109,31 @@ template <bool BF16, int LPG, int PT>
 __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
     const typename ValueIO<BF16>::elem_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ attw,
-    int S, int M, int L, int P, long n_pairs, long pairs_per_batch, long n_chunks,
+    int S, int M, int L, int P, long n_bq /* B*Lq */, long Lq, long n_chunks,
     typename ValueIO<BF16>::elem_t *__restrict__ out)
 {
     typedef ValueIO<BF16> IO;
     typedef typename IO::elem_t elem_t;
     constexpr int CPL = IO::CPL;
     constexpr int D = CPL * LPG;
-    constexpr int G = 64 / LPG;                 // pairs per wave
-    constexpr int PAIRS_PER_BLOCK = G * MSDA_WAVES;
+    constexpr int G = 64 / LPG;                 // queries per wave (all for the SAME head)
+    constexpr int QPB = G * MSDA_WAVES;         // consecutive queries per block
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LP = L * P;
-    const int LPs = LP | 1;                      // odd pair stride in LDS -> conflict-free b64 broadcasts
+    const int LPs = LP | 1;                      // odd stride in LDS -> conflict-free b64 broadcasts
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int grp = lane / LPG;                  // pair within the wave
-    const int sub = lane % LPG;                  // lane within the pair
+    const int grp = lane / LPG;                  // query within the wave
+    const int sub = lane % LPG;                  // lane within the (query, head) pair
     float2_t *s_xy = reinterpret_cast<float2_t *>(smem) + (size_t)wave * G * LPs;
     float *s_w = reinterpret_cast<float *>(smem + (size_t)MSDA_WAVES * G * LPs * sizeof(float2_t)) +
                  (size_t)wave * G * LPs;
 
-    // XCD-aware chunk walk: XCD x (= blockIdx % 8) owns chunks [x*cpx, (x+1)*cpx).
+    // Work decomposition: chunk c = (query tile t = c / M, head m = c % M); a block owns QPB consecutive
+    // queries of ONE head, a wave G consecutive queries: neighbouring queries sample neighbouring pixels, so the
+    // wave's corner gathers keep hitting the same 128-byte lines (vector L1) instead of 8 unrelated head slices.
+    // XCD-aware walk: XCD x (= blockIdx % 8) owns the contiguous chunk range [x*cpx, (x+1)*cpx).
     const int xcd = blockIdx.x & 7;
     const long cpx = (n_chunks + 7) >> 3;
     const int blocks_per_xcd = gridDim.x >> 3;   // gridDim.x is a multiple of 8 (host guarantees)
@@ -137,25 +142,25 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
     for (long j = blockIdx.x >> 3; j < cpx; j += blocks_per_xcd) {
         const long chunk = (long)xcd * cpx + j;
         if (chunk >= n_chunks) break;            // block-uniform
-        const long pair0 = chunk * PAIRS_PER_BLOCK + (long)wave * G;   // first pair of this wave
+        const int m = (int)(chunk % M);
+        const long bq0 = (chunk / M) * QPB + (long)wave * G;   // first (b*Lq+q) of this wave
 
-        // ---- stage loc / weights of the wave's G pairs in LDS (coalesced) ----
+        // ---- stage loc / weights of the wave's G (query, m) pairs in LDS ----
         __syncthreads();                          // previous iteration's LDS reads are done
         for (int i = lane; i < G * LP; i += 64) {
             const int g = i / LP, pnt = i - g * LP;
-            long pr = pair0 + g;
-            pr = pr < n_pairs ? pr : n_pairs - 1;
-            const float2_t xy = *reinterpret_cast<const float2_t *>(loc + (pr * LP + pnt) * 2);
-            s_xy[g * LPs + pnt] = xy;
+            long bq = bq0 + g;
+            bq = bq < n_bq ? bq : n_bq - 1;
+            const long pr = bq * M + m;
+            s_xy[g * LPs + pnt] = *reinterpret_cast<const float2_t *>(loc + (pr * LP + pnt) * 2);
             s_w[g * LPs + pnt] = attw[pr * LP + pnt];
         }
         __syncthreads();
 
-        long pair = pair0 + grp;
-        const bool live = pair < n_pairs;
-        pair = live ? pair : n_pairs - 1;
-        const int m = (int)(pair % M);
-        const long b = pair / pairs_per_batch;
+        long bq = bq0 + grp;
+        const bool live = bq < n_bq;
+        bq = live ? bq : n_bq - 1;
+        const long b = bq / Lq;
         float acc[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
                 }
             }
         }
-        if (live) IO::store(out + pair * D + sub * CPL, acc);
+        if (live) IO::store(out + (bq * M + m) * D + sub * CPL, acc);
     }
 }
 
@@ -350,8 +355,8 @@ static int launch_vec(const void *value, const int64_t *shapes, const int64_t *l
 {
     typedef typename ValueIO<BF16>::elem_t elem_t;
     constexpr int G = 64 / LPG;
-    const long n_pairs = (long)B * Lq * M;
-    const long n_chunks = (n_pairs + G * MSDA_WAVES - 1) / (G * MSDA_WAVES);
+    const long n_bq = (long)B * Lq;
+    const long n_chunks = ((n_bq + G * MSDA_WAVES - 1) / (G * MSDA_WAVES)) * M;
     const int LPs = (L * P) | 1;
     const size_t lds = (size_t)MSDA_WAVES * G * LPs * (sizeof(float2_t) + sizeof(float));
     long want = (n_chunks + 7) / 8;                       // blocks per XCD if one chunk each
@@ -361,7 +366,7 @@ static int launch_vec(const void *value, const int64_t *shapes, const int64_t *l
     const dim3 grid((unsigned)(want * 8)), block(MSDA_BLOCK);
 #define VLLM_MSDA_LAUNCH(PT)                                                                                   \
     hipLaunchKernelGGL((msda_fwd_vec_kernel<BF16, LPG, PT>), grid, block, lds, st, (const elem_t *)value,      \
-                       shapes, lsi, loc, attw, S, M, L, P, n_pairs, (long)Lq * M, n_chunks, (elem_t *)out)
+                       shapes, lsi, loc, attw, S, M, L, P, n_bq, (long)Lq, n_chunks, (elem_t *)out)
     if (P == 4) VLLM_MSDA_LAUNCH(4);
     else if (P == 8) VLLM_MSDA_LAUNCH(8);
     else if (P == 2) VLLM_MSDA_LAUNCH(2);

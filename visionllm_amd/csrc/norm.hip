@@ -1,0 +1,165 @@
+// Row normalisations (bf16 in/out, fp32 statistics) for gfx950.  HBM-bound: 16-byte vector loads, one pass over
+// memory (rows are cached in registers), wave-shuffle reductions, optional multi-wave rows for wide C.
+//
+// Replaces:
+//   InternRMSNorm / apex FusedRMSNorm   VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:33-58
+//       y = weight * bf16( x * rsqrt(mean(x^2) + eps) )      (fp32 statistics, cast, THEN multiply: kept)
+//   QK-RMSNorm over the flattened H*D    :131-134 (applied in place on the q / k column blocks of the qkv buffer)
+//   nn.LayerNorm (CLIP pre_layrnorm / layer_norm1/2, vl_bridge LayerNorm)  transformers CLIPEncoderLayer;
+//       visionllmv2/model/modeling_visionllmv2.py:166-167
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace vllm {
+
+constexpr int NORM_THREADS = 256;
+constexpr int NORM_MAX_CHUNKS = 8;  // 16-byte chunks cached per lane
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// WPR = waves per row (1, 2 or 4).  A 256-thread block handles 4 / WPR rows.
+template <bool RMS, int WPR>
+__global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t *__restrict__ x, int ldx,
+                                                                 const uint16_t *__restrict__ w,
+                                                                 const uint16_t *__restrict__ b, uint16_t *__restrict__ y,
+                                                                 int ldy, long rows, int C, float eps)
+{
+    __shared__ float red[4][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rows_per_block = 4 / WPR;
+    const int rloc = wave / WPR, wsub = wave % WPR;
+    const long row = (long)blockIdx.x * rows_per_block + rloc;
+    const bool live = row < rows;
+    const long r = live ? row : rows - 1;
+    const int nchunk = C >> 3;
+    const uint16_t *xr = x + r * (long)ldx;
+
+    uint4_t v[NORM_MAX_CHUNKS];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+        const int c = (i * WPR + wsub) * 64 + lane;
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const uint4_t *>(xr + c * 8);
+            const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = bf16lo_to_f32(u[k]), bb = bf16hi_to_f32(u[k]);
+                s += a + bb;
+                ss += a * a + bb * bb;
+            }
+        }
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (WPR > 1) {
+        if (lane == 0) { red[wave][0] = s; red[wave][1] = ss; }
+        __syncthreads();
+        s = 0.f; ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < WPR; ++k) { s += red[rloc * WPR + k][0]; ss += red[rloc * WPR + k][1]; }
+    }
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(ss / (float)C + eps);
+    } else {
+        mean = s / (float)C;
+        // second moment about the mean from the cached registers (no cancellation): one more cheap pass
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+            const int c = (i * WPR + wsub) * 64 + lane;
+            if (c < nchunk) {
+                const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = bf16lo_to_f32(u[k]) - mean, bb = bf16hi_to_f32(u[k]) - mean;
+                    var += a * a + bb * bb;
+                }
+            }
+        }
+        var = wave_sum(var);
+        if (WPR > 1) {
+            __syncthreads();
+            if (lane == 0) red[wave][0] = var;
+            __syncthreads();
+            var = 0.f;
+#pragma unroll
+            for (int k = 0; k < WPR; ++k) var += red[rloc * WPR + k][0];
+        }
+        rstd = rsqrtf(var / (float)C + eps);
+    }
+    if (!live) return;
+    uint16_t *yr = y + r * (long)ldy;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+        const int c = (i * WPR + wsub) * 64 + lane;
+        if (c < nchunk) {
+            const uint4_t wv = *reinterpret_cast<const uint4_t *>(w + c * 8);
+            uint4_t bv = {0, 0, 0, 0};
+            if (!RMS && b) bv = *reinterpret_cast<const uint4_t *>(b + c * 8);
+            const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            const uint32_t uw[4] = {wv.x, wv.y, wv.z, wv.w};
+            const uint32_t ub[4] = {bv.x, bv.y, bv.z, bv.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = bf16lo_to_f32(u[k]), bb = bf16hi_to_f32(u[k]);
+                if (RMS) {
+                    // reference order: normalise in fp32, cast to bf16, THEN multiply by the bf16 weight
+                    a = bf16_to_f32(f32_to_bf16(a * rstd)) * bf16lo_to_f32(uw[k]);
+                    bb = bf16_to_f32(f32_to_bf16(bb * rstd)) * bf16hi_to_f32(uw[k]);
+                } else {
+                    a = (a - mean) * rstd * bf16lo_to_f32(uw[k]) + bf16lo_to_f32(ub[k]);
+                    bb = (bb - mean) * rstd * bf16hi_to_f32(uw[k]) + bf16hi_to_f32(ub[k]);
+                }
+                o[k] = pack_bf16x2(a, bb);
+            }
+            uint4_t ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+            *reinterpret_cast<uint4_t *>(yr + c * 8) = ov;
+        }
+    }
+}
+
+int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
+                     long rows, int C, float eps, hipStream_t st)
+{
+    if (rows == 0) return VLLM_OK;
+    VLLM_REQUIRE(x && w && y, "norm: null pointer");
+    VLLM_REQUIRE(C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w) &&
+                     (!b || aligned16(b)),
+                 "norm: C and row strides must be multiples of 8 elements and pointers 16-byte aligned (C=%d)", C);
+    const int nchunk = C / 8;
+    int wpr = 1;
+    while (wpr < 4 && nchunk > 64 * NORM_MAX_CHUNKS * wpr) wpr <<= 1;
+    VLLM_REQUIRE(nchunk <= 64 * NORM_MAX_CHUNKS * wpr, "norm: C=%d too wide (max %d)", C, 64 * NORM_MAX_CHUNKS * 4 * 8);
+    const int rpb = 4 / wpr;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(NORM_THREADS);
+#define L(R, W) hipLaunchKernelGGL((norm_bf16_kernel<R, W>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
+    if (rms) { if (wpr == 1) L(true, 1); else if (wpr == 2) L(true, 2); else L(true, 4); }
+    else     { if (wpr == 1) L(false, 1); else if (wpr == 2) L(false, 2); else L(false, 4); }
+#undef L
+    VLLM_CHECK_LAUNCH("norm_bf16_kernel");
+    return VLLM_OK;
+}
+
+}  // namespace vllm
+
+using namespace vllm;
+
+extern "C" int vllm_rmsnorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, uint16_t *y, int ldy, long rows,
+                                 int C, float eps, vllm_stream_t stream)
+{
+    return norm_bf16_launch(true, x, ldx, weight, nullptr, y, ldy, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int vllm_layernorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, const uint16_t *bias,
+                                   uint16_t *y, int ldy, long rows, int C, float eps, vllm_stream_t stream)
+{
+    return norm_bf16_launch(false, x, ldx, weight, bias, y, ldy, rows, C, eps, (hipStream_t)stream);
+}

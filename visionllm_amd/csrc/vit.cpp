@@ -1,0 +1,195 @@
+// Encoder / projector orchestration behind the C ABI: one host call enqueues every kernel of the image -> visual
+// token path on the caller's stream (no allocation, no synchronisation; workspace provided by the caller).
+//
+// vllm_vit_forward replaces the Python layer loop of InternVisionEncoder.forward
+// (VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:253-270) and of HF CLIPEncoder;
+// vllm_bridge_forward replaces select + pixel_shuffle + vl_bridge (visionllmv2/model/modeling_visionllmv2.py:569-579).
+#include "kernels.hpp"
+
+using namespace vllm;
+
+namespace {
+inline long align256(long x) { return (x + 255) & ~255L; }
+
+struct VitWs {
+    long xn, qkv, ao, hmid, mid, col, h0, h1, total;
+};
+
+VitWs vit_ws_layout(const VllmVitDesc *d, int n)
+{
+    const long g = d->image / d->patch, P = g * g, S = P + 1, M = (long)n * S;
+    VitWs w;
+    long off = 0;
+    auto take = [&](long bytes) { long o = off; off += align256(bytes); return o; };
+    w.xn = take(M * d->hidden * 2);
+    w.qkv = take(M * 3L * d->hidden * 2);
+    w.ao = take(M * d->hidden * 2);
+    w.hmid = take(M * d->hidden * 2);
+    w.mid = take(M * (long)d->inter * 2);
+    w.col = take((long)n * P * d->kpad * 2);
+    w.h0 = take(M * d->hidden * 2);   // ping-pong hidden states for entries the caller does not want
+    w.h1 = take(M * d->hidden * 2);
+    w.total = off;
+    return w;
+}
+
+int check_desc(const VllmVitDesc *d)
+{
+    VLLM_REQUIRE(d, "vit: null descriptor");
+    VLLM_REQUIRE(d->arch == VLLM_ARCH_INTERNVIT || d->arch == VLLM_ARCH_CLIP, "vit: unknown arch %d", d->arch);
+    VLLM_REQUIRE(d->hidden > 0 && d->heads > 0 && d->hidden % d->heads == 0, "vit: hidden %d / heads %d", d->hidden, d->heads);
+    const int hd = d->hidden / d->heads;
+    VLLM_REQUIRE(hd == 64 || hd == 128, "vit: head_dim %d not supported by the attention kernel (64 or 128)", hd);
+    VLLM_REQUIRE(d->hidden % 64 == 0 && d->inter % 64 == 0, "vit: hidden/intermediate must be multiples of 64");
+    VLLM_REQUIRE(d->patch > 0 && d->image % d->patch == 0, "vit: image %d not divisible by patch %d", d->image, d->patch);
+    VLLM_REQUIRE(d->kpad % 64 == 0 && d->kpad >= 3 * d->patch * d->patch, "vit: kpad %d", d->kpad);
+    VLLM_REQUIRE(d->num_layers >= 0 && (d->num_layers == 0 || d->layers), "vit: layers missing");
+    VLLM_REQUIRE(d->patch_w && d->cls && d->pos, "vit: embedding parameters missing");
+    VLLM_REQUIRE(d->act == VLLM_EPI_GELU || d->act == VLLM_EPI_QUICK_GELU, "vit: act %d", d->act);
+    return VLLM_OK;
+}
+}  // namespace
+
+extern "C" int vllm_vit_desc_sizeof(void) { return (int)sizeof(VllmVitDesc); }
+extern "C" int vllm_vit_layer_sizeof(void) { return (int)sizeof(VllmVitLayer); }
+extern "C" int vllm_bridge_desc_sizeof(void) { return (int)sizeof(VllmBridgeDesc); }
+
+extern "C" long vllm_vit_workspace_bytes(const VllmVitDesc *d, int n_tiles)
+{
+    if (check_desc(d) != VLLM_OK || n_tiles < 0) return -1;
+    return vit_ws_layout(d, n_tiles).total;
+}
+
+#define TRY(x) do { int rc__ = (x); if (rc__ != VLLM_OK) return rc__; } while (0)
+
+extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n, uint16_t *const *hs, void *workspace,
+                                long ws_bytes, vllm_stream_t stream)
+{
+    TRY(check_desc(d));
+    VLLM_REQUIRE(n >= 0, "vit: negative tile count");
+    if (n == 0) return VLLM_OK;
+    VLLM_REQUIRE(pixels && hs && workspace, "vit: null pointer");
+    const VitWs w = vit_ws_layout(d, n);
+    VLLM_REQUIRE(ws_bytes >= w.total, "vit: workspace too small (%ld < %ld)", ws_bytes, w.total);
+    VLLM_REQUIRE(hs[d->num_layers], "vit: the last hidden state must be provided");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const int C = d->hidden, H = d->heads, D = C / H, I = d->inter;
+    const int g = d->image / d->patch, P = g * g, S = P + 1;
+    const long M = (long)n * S;
+    VLLM_REQUIRE(M < (1L << 31) / 4, "vit: too many tokens");
+    uint16_t *xn = (uint16_t *)(ws + w.xn), *qkv = (uint16_t *)(ws + w.qkv), *ao = (uint16_t *)(ws + w.ao);
+    uint16_t *hmid = (uint16_t *)(ws + w.hmid), *mid = (uint16_t *)(ws + w.mid), *col = (uint16_t *)(ws + w.col);
+    uint16_t *pp[2] = {(uint16_t *)(ws + w.h0), (uint16_t *)(ws + w.h1)};
+    const bool clip = d->arch == VLLM_ARCH_CLIP;
+    const float scale = 1.0f / sqrtf((float)D);
+
+    auto state = [&](int i) -> uint16_t * { return hs[i] ? hs[i] : pp[i & 1]; };
+
+    // ---- embeddings: im2col gather -> GEMM (+bias +pos, rows scattered past CLS) ; CLS rows ----
+    uint16_t *emb = clip ? hmid : state(0);   // CLIP: pre_layrnorm produces hidden_states[0]
+    TRY(im2col_launch(pixels, d->pixel_is_f32, col, n, d->image, d->patch, d->kpad, st));
+    TRY(gemm(st, EPI_EMBED, col, d->kpad, d->patch_w, d->kpad, d->patch_b, emb, C, n * P, C, d->kpad, nullptr, d->pos, C, P));
+    TRY(cls_rows_launch(d->cls, d->pos, emb, n, S, C, st));
+    if (clip) {
+        VLLM_REQUIRE(d->pre_ln_w && d->pre_ln_b, "vit: CLIP needs pre_layrnorm");
+        TRY(norm_bf16_launch(false, emb, C, d->pre_ln_w, d->pre_ln_b, state(0), C, M, C, d->eps, st));
+    }
+
+    for (int i = 0; i < d->num_layers; ++i) {
+        const VllmVitLayer &L = d->layers[i];
+        const uint16_t *h = state(i);
+        uint16_t *hout = state(i + 1);
+        VLLM_REQUIRE(L.norm1_w && L.qkv_w && L.proj_w && L.norm2_w && L.fc1_w && L.fc2_w, "vit: layer %d parameters missing", i);
+        // attention block
+        TRY(norm_bf16_launch(!clip, h, C, L.norm1_w, L.norm1_b, xn, C, M, C, d->eps, st));
+        TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C));
+        if (L.q_norm_w) TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st));
+        if (L.k_norm_w) TRY(norm_bf16_launch(true, qkv + C, 3 * C, L.k_norm_w, nullptr, qkv + C, 3 * C, M, C, d->eps, st));
+        {
+            AttnArgs a;
+            a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.out = ao;
+            a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * C;
+            a.q_ts = a.k_ts = a.v_ts = 3 * C;
+            a.q_hs = a.k_hs = a.v_hs = D;
+            a.B = n; a.S = S; a.H = H; a.nqt = 0;
+            a.scale_log2e = scale * 1.4426950408889634f;
+            TRY(attn_fwd_launch(a, D, st));
+        }
+        TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C));
+        // MLP block
+        TRY(norm_bf16_launch(!clip, hmid, C, L.norm2_w, L.norm2_b, xn, C, M, C, d->eps, st));
+        TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C));
+        TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C));
+    }
+    return VLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct BridgeWs { long a, b, c, total; };
+BridgeWs bridge_ws_layout(const VllmBridgeDesc *d, int n, int T_in)
+{
+    const long T = d->pixel_shuffle ? T_in / 4 : T_in;
+    const long rows = (long)n * T;
+    BridgeWs w;
+    long off = 0;
+    auto take = [&](long bytes) { long o = off; off += align256(bytes); return o; };
+    w.a = take(d->pixel_shuffle ? rows * d->in_features * 2 : 0);                       // shuffled features
+    w.b = take(d->kind == VLLM_BRIDGE_INTERNVL_MLP ? rows * d->in_features * 2 : 0);   // LayerNorm output
+    w.c = take(d->depth > 1 ? 2 * align256(rows * (long)d->out_features * 2) : 0);     // MLP intermediates
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" long vllm_bridge_workspace_bytes(const VllmBridgeDesc *d, int n_tiles, int T_in)
+{
+    if (!d || n_tiles < 0 || T_in < 0) return -1;
+    return bridge_ws_layout(d, n_tiles, T_in).total;
+}
+
+extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidden, int n, int T_in, int C, uint16_t *out,
+                                   void *workspace, long ws_bytes, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(d && d->depth >= 1 && d->depth <= 4, "bridge: bad descriptor");
+    if (n == 0) return VLLM_OK;
+    VLLM_REQUIRE(hidden && out, "bridge: null pointer");
+    const BridgeWs w = bridge_ws_layout(d, n, T_in);
+    VLLM_REQUIRE(w.total == 0 || (workspace && ws_bytes >= w.total), "bridge: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const int S = T_in + (d->skip_cls ? 1 : 0);
+    const int Cin = d->in_features, Cout = d->out_features;
+    VLLM_REQUIRE(Cin == (d->pixel_shuffle ? 4 * C : C), "bridge: in_features %d does not match C=%d", Cin, C);
+    VLLM_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "bridge: feature sizes must be multiples of 64");
+    const uint16_t *x = hidden;
+    int ldx = C, xP = d->skip_cls ? T_in : 0;   // hidden[:, 1:] is read in place (the GEMM loader skips CLS rows)
+    long rows = (long)n * T_in;
+    if (d->pixel_shuffle) {
+        const int hw = (int)(sqrtf((float)T_in) + 0.5f);
+        VLLM_REQUIRE(hw * hw == T_in && hw % 2 == 0, "bridge: pixel_shuffle needs an even square token grid (T=%d)", T_in);
+        uint16_t *shuf = (uint16_t *)(ws + w.a);
+        TRY(pixel_shuffle_launch(hidden, (long)S * C, C, d->skip_cls ? 1 : 0, shuf, n, hw, C, st));
+        x = shuf; ldx = Cin; xP = 0; rows = (long)n * (T_in / 4);
+    }
+    if (d->kind == VLLM_BRIDGE_INTERNVL_MLP) {
+        VLLM_REQUIRE(d->ln_w && d->ln_b, "bridge: internvl_mlp needs LayerNorm parameters");
+        VLLM_REQUIRE(xP == 0, "bridge: internvl_mlp without pixel_shuffle is not wired (LayerNorm reads contiguous rows)");
+        uint16_t *ln = (uint16_t *)(ws + w.b);
+        TRY(norm_bf16_launch(false, x, ldx, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st));
+        x = ln; ldx = Cin;
+    }
+    uint16_t *tmp[2] = {(uint16_t *)(ws + w.c), (uint16_t *)(ws + w.c + align256(rows * (long)Cout * 2))};
+    int K = Cin;
+    for (int i = 0; i < d->depth; ++i) {
+        VLLM_REQUIRE(d->w[i], "bridge: weight %d missing", i);
+        const bool last = i == d->depth - 1;
+        uint16_t *y = last ? out : tmp[i & 1];
+        // GELU sits between Linear i and Linear i+1 -> fused into Linear i's epilogue
+        TRY(gemm(st, last ? EPI_BIAS : EPI_GELU, x, ldx, d->w[i], K, d->b[i], y, Cout, (int)rows, Cout, K, nullptr, nullptr,
+                 0, 0, i == 0 ? xP : 0));
+        x = y; ldx = Cout; K = Cout;
+    }
+    return VLLM_OK;
+}

@@ -1,0 +1,51 @@
+"""Data-parallel sharding of images and the all-gather of visual tokens before the LLM stage.
+
+The reference is pure data parallel (torchrun + DistributedSampler, VisionLLMv2/visionllmv2/train/train.py:586-588);
+every rank feeds its own LLM replica, so there is no token exchange in the reference.  The north star adds ONE
+exchange step: an all-gather of the projector output ``[n_tiles_r, T, C_llm]`` (bf16, 84-189 MB per rank at 8 images
+x 5 tiles) over RCCL/xGMI.  Tiles per rank vary (1-7 tiles per image), so the counts are exchanged first and the
+payload is padded to the maximum (``all_gather_into_tensor`` needs equal shards).  On ROCm the ``nccl`` backend IS
+RCCL; ``gloo`` is used by the CPU tests.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_images(tiles_per_image: Sequence[int], world_size: int) -> List[List[int]]:
+    """Assign whole images to ranks, balancing TILE counts (greedy longest-processing-time), keeping every
+    image's tiles on one rank so ``split_sizes`` stay contiguous (modeling_visionllmv2.py:563, 587-588).
+    Returns image indices per rank (each list sorted)."""
+    loads = [0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    order = sorted(range(len(tiles_per_image)), key=lambda i: (-tiles_per_image[i], i))
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += tiles_per_image[i]
+    return [sorted(x) for x in out]
+
+
+def all_gather_visual_tokens(tokens: torch.Tensor, group=None) -> Tuple[torch.Tensor, List[int]]:
+    """tokens [n_tiles_r, T, C] -> ([sum_r n_tiles_r, T, C] in rank order, tiles per rank).
+
+    One small all-gather of the counts, one large all-gather of the (padded) payload."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tokens, [tokens.shape[0]]
+    ws = dist.get_world_size(group)
+    n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=tokens.device)
+    counts = torch.empty(ws, dtype=torch.int64, device=tokens.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts_l = [int(c) for c in counts.tolist()]
+    mx = max(counts_l)
+    T, C = tokens.shape[1], tokens.shape[2]
+    if tokens.shape[0] != mx:
+        pad = torch.zeros((mx, T, C), dtype=tokens.dtype, device=tokens.device)
+        pad[: tokens.shape[0]] = tokens
+        tokens = pad
+    out = torch.empty((ws * mx, T, C), dtype=tokens.dtype, device=tokens.device)
+    dist.all_gather_into_tensor(out, tokens.contiguous(), group=group)
+    if all(c == mx for c in counts_l):
+        return out, counts_l
+    return torch.cat([out[r * mx: r * mx + counts_l[r]] for r in range(ws)], 0), counts_l

@@ -1,0 +1,96 @@
+"""Shared host logic of the two vision-encoder mirrors (InternViT, CLIP): parameter packing into the C ABI
+descriptor, hidden-state allocation, the forward call."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _require_bf16_cuda(name, t):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor: the native vision encoder has no CPU path")
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f"{name} must be bfloat16 (got {t.dtype}); load the model with torch_dtype=torch.bfloat16 "
+                           "as the reference does (train/train.py:375)")
+
+
+class EncoderPlan:
+    """Device pointers of every parameter, packed once and refreshed when a parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.desc = None
+        self.layers = None
+        self.keep = []  # tensors owned by the plan (padded / fused copies)
+
+    @staticmethod
+    def signature(params):
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+
+
+def padded_patch_weight(conv_weight, kpad):
+    """Conv2d weight [C,3,ps,ps] -> [C, kpad] (k = c*ps*ps + ky*ps + kx, zero padded)."""
+    C = conv_weight.shape[0]
+    w = conv_weight.detach().reshape(C, -1)
+    out = torch.zeros((C, kpad), dtype=w.dtype, device=w.device)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+def kpad_for(patch):
+    k = 3 * patch * patch
+    return (k + 63) // 64 * 64
+
+
+def run_encoder(desc, pixel_values, num_layers, hidden_size, keep=None):
+    """Allocate hidden states and call vllm_vit_forward.  ``keep``: None = materialise all L+1 states (what the
+    reference does with output_hidden_states=True), or an iterable of indices (negative allowed) to keep."""
+    lib = _lib.lib()
+    if pixel_values.dim() != 4 or pixel_values.shape[1] != 3:
+        raise ValueError(f"wrong pixel_values size: {tuple(pixel_values.shape)}")
+    if not pixel_values.is_cuda:
+        raise RuntimeError("pixel_values must be a CUDA tensor: the native vision encoder has no CPU path")
+    if pixel_values.shape[2] != desc.image or pixel_values.shape[3] != desc.image:
+        raise ValueError(f"pixel_values must be {desc.image}x{desc.image}, got {tuple(pixel_values.shape[2:])}")
+    if pixel_values.dtype not in (torch.bfloat16, torch.float32):
+        pixel_values = pixel_values.to(torch.bfloat16)
+    pixel_values = pixel_values.contiguous()
+    desc.pixel_is_f32 = 1 if pixel_values.dtype == torch.float32 else 0
+    n = pixel_values.shape[0]
+    g = desc.image // desc.patch
+    S = g * g + 1
+    dev = pixel_values.device
+    L = num_layers
+    if keep is None:
+        want = set(range(L + 1))
+    else:
+        want = {(i + L + 1) % (L + 1) for i in keep} | {L}
+    states = [torch.empty((n, S, hidden_size), dtype=torch.bfloat16, device=dev) if i in want else None
+              for i in range(L + 1)]
+    ptrs = (ctypes.c_void_p * (L + 1))(*[s.data_ptr() if s is not None else None for s in states])
+    with torch.cuda.device(dev):
+        ws_bytes = lib.vllm_vit_workspace_bytes(ctypes.byref(desc), n)
+        if ws_bytes < 0:
+            raise RuntimeError("vllm_vit_workspace_bytes: " + lib.vllm_last_error().decode())
+        ws = _lib.workspace(dev, ws_bytes)
+        _lib.check(lib.vllm_vit_forward(ctypes.byref(desc), _lib.ptr(pixel_values), n, ptrs, _lib.ptr(ws), ws_bytes,
+                                        _lib.current_stream(dev)), "vllm_vit_forward")
+    return states
+
+
+class LazyHiddenStates(tuple):
+    """Tuple of L+1 hidden states; entries that were not materialised are None (only with keep=...)."""
+
+
+def model_output(last_hidden_state, pooler_output, hidden_states, return_dict=True):
+    if not return_dict:
+        return (last_hidden_state, pooler_output) + ((hidden_states,) if hidden_states is not None else ())
+    try:
+        from transformers.modeling_outputs import BaseModelOutputWithPooling
+        return BaseModelOutputWithPooling(last_hidden_state=last_hidden_state, pooler_output=pooler_output,
+                                          hidden_states=hidden_states, attentions=None)
+    except Exception:  # transformers not importable: a minimal stand-in with the attributes the caller reads
+        from types import SimpleNamespace
+        return SimpleNamespace(last_hidden_state=last_hidden_state, pooler_output=pooler_output,
+                               hidden_states=hidden_states, attentions=None)
