@@ -63,6 +63,10 @@ def lib():
         raise RuntimeError(
             f"{path} is missing: the HIP extension has not been built. Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` (or `make -C visionllm_amd/csrc`). There is no CPU fallback.")
+    # Load torch FIRST: the extension must bind to the HIP runtime (libamdhip64) that PyTorch-ROCm ships and has
+    # initialised.  Loading ours first pulls in /opt/rocm's copy and the two runtimes then disagree about devices
+    # ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     L = ctypes.CDLL(path)
     for name, (restype, argtypes) in parse_header().items():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

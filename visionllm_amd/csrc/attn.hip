@@ -54,13 +54,6 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
     }
 }
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi)
-{
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
 template <int D>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs a)
 {
@@ -163,7 +156,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 const float p0 = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
                 const float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] - m_new);
                 psum += p0 + p1;
-                pk[kb][r >> 1] = cvt_pk_bf16(p0, p1);
+                pk[kb][r >> 1] = pack_bf16x2(p0, p1);
             }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -227,8 +220,8 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    if (D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, lds, st, a);
+    if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64>), grid, block, lds, st, a);
+    else VLLM_LAUNCH((attn_fwd_kernel<128>), grid, block, lds, st, a);
     VLLM_CHECK_LAUNCH("attn_fwd_kernel");
     return VLLM_OK;
 }

@@ -19,6 +19,14 @@ void set_error(const char *fmt, ...);
         }                                        \
     } while (0)
 
+// hipGetLastError() is sticky per thread: a benign failure inside the host framework (e.g. a capability probe)
+// would otherwise be reported as OUR launch failing, so every launch goes through VLLM_LAUNCH (clear, then launch).
+#define VLLM_LAUNCH(kernel, grid, block, lds, st, ...)                         \
+    do {                                                                       \
+        (void)hipGetLastError();                                               \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);         \
+    } while (0)
+
 #define VLLM_CHECK_LAUNCH(what)                                                        \
     do {                                                                               \
         hipError_t e__ = hipGetLastError();                                            \
@@ -35,17 +43,15 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t pair) { return __uint_as_float(pair << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t pair) { return __uint_as_float(pair & 0xffff0000u); }
-// round-to-nearest-even, NaN preserved (quiet)
-__device__ __forceinline__ uint16_t f32_to_bf16(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even: let the compiler select v_cvt_pk_bf16_f32 (gfx950) -- it also inserts the
+// wait state the trans-op -> VALU hazard needs (a hand-written asm cvt right behind v_exp_f32 read a stale value).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const float2v_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 typedef float float4_t __attribute__((ext_vector_type(4)));

@@ -107,9 +107,9 @@ int im2col_launch(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int 
     const int g = img / ps;
     const long nseg = (long)N * g * g * 3 * ps;
     if (pixel_is_f32)
-        hipLaunchKernelGGL((im2col_kernel<float>), dim3(grid_for(nseg)), dim3(256), 0, st, (const float *)pixels, A, N, img, ps, g, Kpad);
+        VLLM_LAUNCH((im2col_kernel<float>), dim3(grid_for(nseg)), dim3(256), 0, st, (const float *)pixels, A, N, img, ps, g, Kpad);
     else
-        hipLaunchKernelGGL((im2col_kernel<uint16_t>), dim3(grid_for(nseg)), dim3(256), 0, st, (const uint16_t *)pixels, A, N, img, ps, g, Kpad);
+        VLLM_LAUNCH((im2col_kernel<uint16_t>), dim3(grid_for(nseg)), dim3(256), 0, st, (const uint16_t *)pixels, A, N, img, ps, g, Kpad);
     VLLM_CHECK_LAUNCH("im2col_kernel");
     return VLLM_OK;
 }
@@ -117,7 +117,7 @@ int im2col_launch(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int 
 int cls_rows_launch(const uint16_t *cls, const uint16_t *pos, uint16_t *hidden, int N, int S, int C, hipStream_t st)
 {
     if (N == 0) return VLLM_OK;
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((long)N * C)), dim3(256), 0, st, cls, pos, hidden, N, S, C);
+    VLLM_LAUNCH(cls_rows_kernel, dim3(grid_for((long)N * C)), dim3(256), 0, st, cls, pos, hidden, N, S, C);
     VLLM_CHECK_LAUNCH("cls_rows_kernel");
     return VLLM_OK;
 }
@@ -129,7 +129,7 @@ int pixel_shuffle_launch(const uint16_t *in, long in_tile_stride, int ldin, int 
     VLLM_REQUIRE(hw % 2 == 0 && C % 8 == 0 && ldin % 8 == 0 && in_tile_stride % 8 == 0 && aligned16(in) && aligned16(out),
                  "pixel_shuffle: needs even grid, C %% 8 == 0 and 16-byte alignment");
     if (N == 0) return VLLM_OK;
-    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((long)N * hw * hw * C / 8)), dim3(256), 0, st, in,
+    VLLM_LAUNCH(pixel_shuffle_kernel, dim3(grid_for((long)N * hw * hw * C / 8)), dim3(256), 0, st, in,
                        in_tile_stride, ldin, tok0, out, N, hw, C);
     VLLM_CHECK_LAUNCH("pixel_shuffle_kernel");
     return VLLM_OK;
@@ -140,7 +140,7 @@ int drop_cls_launch(const uint16_t *in, long in_tile_stride, int ldin, uint16_t 
     VLLM_REQUIRE(in && out && C % 8 == 0 && ldin % 8 == 0 && in_tile_stride % 8 == 0 && aligned16(in) && aligned16(out),
                  "drop_cls: bad arguments");
     if (N == 0) return VLLM_OK;
-    hipLaunchKernelGGL(drop_cls_kernel, dim3(grid_for((long)N * T * C / 8)), dim3(256), 0, st, in, in_tile_stride, ldin,
+    VLLM_LAUNCH(drop_cls_kernel, dim3(grid_for((long)N * T * C / 8)), dim3(256), 0, st, in, in_tile_stride, ldin,
                        out, N, T, C);
     VLLM_CHECK_LAUNCH("drop_cls_kernel");
     return VLLM_OK;

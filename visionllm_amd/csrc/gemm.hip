@@ -179,7 +179,7 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;   // generic mapping pads the X-panel count to 8
     const dim3 grid((unsigned)tiles), block(GEMM_THREADS);
     const size_t lds = 4 * TILE_BYTES;
-#define L(E) hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, lds, st, a)
+#define L(E) VLLM_LAUNCH((gemm_bf16_kernel<E>), grid, block, lds, st, a)
     switch (epi) {
     case EPI_BIAS: L(EPI_BIAS); break;
     case EPI_GELU: L(EPI_GELU); break;

@@ -365,7 +365,7 @@ static int launch_vec(const void *value, const int64_t *shapes, const int64_t *l
     if (want < 1) want = 1;
     const dim3 grid((unsigned)(want * 8)), block(MSDA_BLOCK);
 #define VLLM_MSDA_LAUNCH(PT)                                                                                   \
-    hipLaunchKernelGGL((msda_fwd_vec_kernel<BF16, LPG, PT>), grid, block, lds, st, (const elem_t *)value,      \
+    VLLM_LAUNCH((msda_fwd_vec_kernel<BF16, LPG, PT>), grid, block, lds, st, (const elem_t *)value,      \
                        shapes, lsi, loc, attw, S, M, L, P, n_bq, (long)Lq, n_chunks, (elem_t *)out)
     if (P == 4) VLLM_MSDA_LAUNCH(4);
     else if (P == 8) VLLM_MSDA_LAUNCH(8);
@@ -410,7 +410,7 @@ static int launch_generic_fwd(const T *value, const int64_t *shapes, const int64
     long blocks = (n_out + 255) / 256;
     const long cap = (long)cu_count() * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((msda_fwd_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi,
+    VLLM_LAUNCH((msda_fwd_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi,
                        loc, attw, S, M, D, L, P, n_out, (long)Lq * M, out);
     VLLM_CHECK_LAUNCH("msda_fwd_generic_kernel");
     return VLLM_OK;
@@ -426,7 +426,7 @@ static int launch_generic_bwd(const T *value, const int64_t *shapes, const int64
     long blocks = (n_points + 255) / 256;
     const long cap = (long)cu_count() * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((msda_bwd_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi,
+    VLLM_LAUNCH((msda_bwd_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi,
                        loc, attw, grad_out, S, M, D, L, P, n_points, (long)Lq * M, gv, gl, gw);
     VLLM_CHECK_LAUNCH("msda_bwd_generic_kernel");
     return VLLM_OK;
@@ -481,7 +481,7 @@ extern "C" int vllm_msda_sample_index_f32(const int64_t *shapes, const float *lo
     VLLM_REQUIRE(shapes && loc && h_low && w_low && mask, "msda_sample_index: null pointer");
     long blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(msda_sample_index_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shapes,
+    VLLM_LAUNCH(msda_sample_index_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shapes,
                        loc, L, P, n, h_low, w_low, mask);
     VLLM_CHECK_LAUNCH("msda_sample_index_kernel");
     return VLLM_OK;

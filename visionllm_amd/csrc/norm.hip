@@ -140,7 +140,7 @@ int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, co
     VLLM_REQUIRE(nchunk <= 64 * NORM_MAX_CHUNKS * wpr, "norm: C=%d too wide (max %d)", C, 64 * NORM_MAX_CHUNKS * 4 * 8);
     const int rpb = 4 / wpr;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(NORM_THREADS);
-#define L(R, W) hipLaunchKernelGGL((norm_bf16_kernel<R, W>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
+#define L(R, W) VLLM_LAUNCH((norm_bf16_kernel<R, W>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
     if (rms) { if (wpr == 1) L(true, 1); else if (wpr == 2) L(true, 2); else L(true, 4); }
     else     { if (wpr == 1) L(false, 1); else if (wpr == 2) L(false, 2); else L(false, 4); }
 #undef L
