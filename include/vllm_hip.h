@@ -99,6 +99,10 @@ int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int
 #define VLLM_EPI_QUICK_GELU 2  /* y = z*sigmoid(1.702 z)                          (CLIP MLP) */
 #define VLLM_EPI_RESIDUAL 3    /* y = res + (x W^T + b) * scale                   (LayerScale + residual, modeling_intern_vit.py:206-208) */
 #define VLLM_EPI_EMBED 4       /* patch embedding: rows scattered past the CLS slot, + position embedding */
+/* Kernel choice is automatic (256x256 8-phase schedule for M,N >= 1024, 128x128 otherwise); OR one of these into
+ * `epilogue` to force a schedule (parity tests / tuning only). */
+#define VLLM_GEMM_FORCE_128 0x100
+#define VLLM_GEMM_FORCE_256 0x200
 
 /* Y[M,N] = epilogue(X[M,K] @ W[N,K]^T + bias).  Replaces F.linear / nn.Conv2d-as-GEMM on the path
  * (modeling_intern_vit.py:112,124,128,141,172-178; modeling_visionllmv2.py:162-182).

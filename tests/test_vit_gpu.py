@@ -48,7 +48,8 @@ def close(out, ref, tol=1e-2, what=""):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (577, 1024, 1024), (1000, 3200, 192), (77, 64, 640),
                                    (2 * 577, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-def test_gemm_epilogues(M, N, K, epi):
+@pytest.mark.parametrize("force", [0x100, 0x200])   # both schedules: 128x128 2-stage and 256x256 8-phase
+def test_gemm_epilogues(M, N, K, epi, force):
     torch.manual_seed(M + N + K + epi)
     x = bf(torch.randn(M, K, device=DEV))
     w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
@@ -56,8 +57,8 @@ def test_gemm_epilogues(M, N, K, epi):
     ls = bf(0.1 + 0.05 * torch.randn(N, device=DEV))
     res = bf(torch.randn(M, N, device=DEV))
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi, P(ls) if epi == 3 else None,
-                                         P(res) if epi == 3 else None, N, 0, stream()))
+    _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi | force,
+                                         P(ls) if epi == 3 else None, P(res) if epi == 3 else None, N, 0, stream()))
     z = x.float() @ w.float().t() + b.float()
     if epi == 1:
         z = V.gelu_erf(z)
@@ -68,17 +69,38 @@ def test_gemm_epilogues(M, N, K, epi):
     close(y, z, 1e-2, f"gemm epi {epi}")
 
 
-def test_gemm_transpose_detecting():
+@pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512)])
+def test_gemm_transpose_detecting(force, M):
     """A = I-like and asymmetric B (cdna guide G9): catches swapped operands / transposed stores."""
-    M = N = K = 128
+    N = K = M
     x = torch.zeros(M, K, device=DEV)
     x[torch.arange(M), torch.arange(K)] = 1.0
     w = torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 / 251.0
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     xb, wb = bf(x), bf(w)   # keep the bf16 tensors alive while the kernel runs
-    _lib.check(_lib.lib().vllm_gemm_bf16(P(xb), P(wb), None, P(y), M, N, K, K, K, N, 0, None, None, 0, 0, stream()))
+    _lib.check(_lib.lib().vllm_gemm_bf16(P(xb), P(wb), None, P(y), M, N, K, K, K, N, force, None, None, 0, 0, stream()))
     torch.cuda.synchronize()
     assert torch.equal(y.float(), wb.float().t()), "identity x asymmetric W must be exact"
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 4096), (23080, 3072, 1024), (5125, 9600, 3200)])
+def test_gemm256_pipeline_race_screen(M, N, K):
+    """8-phase schedule: long K (many ring refills), ragged M/N edges, repeated runs must be bit-identical and
+    match the 128x128 kernel to rounding (the two kernels sum k in the same order inside a 64-wide tile)."""
+    torch.manual_seed(M + K)
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    ys = []
+    for force in (0x200, 0x200, 0x200, 0x100):
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, force, None, None, 0, 0, stream()))
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    close(ys[0], ys[3], 4e-3, "256 vs 128 kernel")
+    ref = x[:257].float() @ w.float().t() + b.float()
+    close(ys[0][:257], ref, 1e-2, "256 kernel vs fp32")
 
 
 def test_gemm_rejects_bad_shapes():

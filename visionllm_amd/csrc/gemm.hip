@@ -18,6 +18,7 @@
 // an XCD owns a fixed subset of W panels (they stay in its 4 MiB L2) and streams the X panels.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace vllm {
 
@@ -27,9 +28,6 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GEMM_THREADS = 256;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 // Stage one 128 x 64 bf16 operand tile: 16 segments of 8 rows, 4 segments per wave, one LDS-DMA per segment.
 __device__ __forceinline__ void stage_tile(const uint16_t *__restrict__ src, int ld, int row0, int nrows, int k0,
@@ -120,46 +118,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + kq * 4;
         if (n >= a.N) continue;
-        float bia[4] = {0.f, 0.f, 0.f, 0.f}, scl[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.bias) {
-            const uint2_t b = *reinterpret_cast<const uint2_t *>(a.bias + n);
-            bia[0] = bf16lo_to_f32(b.x); bia[1] = bf16hi_to_f32(b.x); bia[2] = bf16lo_to_f32(b.y); bia[3] = bf16hi_to_f32(b.y);
-        }
-        if (EPI == EPI_RESIDUAL && a.scale) {
-            const uint2_t s = *reinterpret_cast<const uint2_t *>(a.scale + n);
-            scl[0] = bf16lo_to_f32(s.x); scl[1] = bf16hi_to_f32(s.x); scl[2] = bf16lo_to_f32(s.y); scl[3] = bf16hi_to_f32(s.y);
-        }
+        const EpiCols cols = epi_cols<EPI>(a, n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wm * 64 + j * 16 + fr;
             if (m >= a.M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bia[r];
-            size_t orow = (size_t)m;
-            if (EPI == EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            } else if (EPI == EPI_QUICK_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-            } else if (EPI == EPI_RESIDUAL) {
-                const uint2_t rr = *reinterpret_cast<const uint2_t *>(a.res + (size_t)m * a.ldr + n);
-                v[0] = bf16lo_to_f32(rr.x) + v[0] * scl[0]; v[1] = bf16hi_to_f32(rr.x) + v[1] * scl[1];
-                v[2] = bf16lo_to_f32(rr.y) + v[2] * scl[2]; v[3] = bf16hi_to_f32(rr.y) + v[3] * scl[3];
-            } else if (EPI == EPI_EMBED) {
-                const int img = m / a.P, p = m - img * a.P;
-                orow = (size_t)img * (a.P + 1) + 1 + p;
-                const uint2_t pp = *reinterpret_cast<const uint2_t *>(a.res + (size_t)(1 + p) * a.ldr + n);
-                v[0] += bf16lo_to_f32(pp.x); v[1] += bf16hi_to_f32(pp.x); v[2] += bf16lo_to_f32(pp.y); v[3] += bf16hi_to_f32(pp.y);
-            }
-            uint2_t o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2_t *>(a.Y + orow * a.ldy + n) = o;
+            epi_store<EPI>(a, m, n, acc[i][j], cols);
         }
     }
 }
+
+int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st);   // gemm256.hip
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 {
@@ -172,6 +141,8 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                  "gemm: operands must be 16-byte aligned with row strides multiple of 8 elements");
     VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
     VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
+    if (a.variant != 1 && (a.variant == 2 || (a.N >= 1024 && a.M >= 1024)))
+        return gemm256_bf16_launch(epi, a, st);
     a.mt = ceil_div(a.M, BM);
     a.nt = ceil_div(a.N, BN);
     long tiles;
@@ -204,6 +175,7 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     VLLM_REQUIRE(X && W && Y, "vllm_gemm_bf16: null pointer");
     GemmArgs a;
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
-    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0;
-    return gemm_bf16_launch(epilogue, a, (hipStream_t)stream);
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override();
+    if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;   // VLLM_GEMM_FORCE_* (tests / tuning)
+    return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
 }

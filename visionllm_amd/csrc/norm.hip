@@ -13,7 +13,7 @@
 namespace vllm {
 
 constexpr int NORM_THREADS = 256;
-constexpr int NORM_MAX_CHUNKS = 8;  // 16-byte chunks cached per lane
+constexpr int NORM_MAX_CHUNKS = 8;  // upper bound of 16-byte chunks cached per lane (template MAXCH picks 1/2/4/8)
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -23,7 +23,7 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // WPR = waves per row (1, 2 or 4).  A 256-thread block handles 4 / WPR rows.
-template <bool RMS, int WPR>
+template <bool RMS, int WPR, int MAXCH>
 __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t *__restrict__ x, int ldx,
                                                                  const uint16_t *__restrict__ w,
                                                                  const uint16_t *__restrict__ b, uint16_t *__restrict__ y,
@@ -39,10 +39,10 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
     const int nchunk = C >> 3;
     const uint16_t *xr = x + r * (long)ldx;
 
-    uint4_t v[NORM_MAX_CHUNKS];
+    uint4_t v[MAXCH];
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAXCH; ++i) {
         const int c = (i * WPR + wsub) * 64 + lane;
         if (c < nchunk) {
             v[i] = *reinterpret_cast<const uint4_t *>(xr + c * 8);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
         // second moment about the mean from the cached registers (no cancellation): one more cheap pass
         float var = 0.f;
 #pragma unroll
-        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+        for (int i = 0; i < MAXCH; ++i) {
             const int c = (i * WPR + wsub) * 64 + lane;
             if (c < nchunk) {
                 const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
     if (!live) return;
     uint16_t *yr = y + r * (long)ldy;
 #pragma unroll
-    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAXCH; ++i) {
         const int c = (i * WPR + wsub) * 64 + lane;
         if (c < nchunk) {
             const uint4_t wv = *reinterpret_cast<const uint4_t *>(w + c * 8);
@@ -138,12 +138,18 @@ int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, co
     int wpr = 1;
     while (wpr < 4 && nchunk > 64 * NORM_MAX_CHUNKS * wpr) wpr <<= 1;
     VLLM_REQUIRE(nchunk <= 64 * NORM_MAX_CHUNKS * wpr, "norm: C=%d too wide (max %d)", C, 64 * NORM_MAX_CHUNKS * 4 * 8);
+    // prefer <= 4 cached chunks per lane (58 VGPRs, full occupancy) by spreading wide rows over 2 or 4 waves
+    while (wpr < 4 && nchunk > 64 * 4 * wpr) wpr <<= 1;
+    const int per_lane = (nchunk + 64 * wpr - 1) / (64 * wpr);
+    const int maxch = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 8;
     const int rpb = 4 / wpr;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(NORM_THREADS);
-#define L(R, W) VLLM_LAUNCH((norm_bf16_kernel<R, W>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
-    if (rms) { if (wpr == 1) L(true, 1); else if (wpr == 2) L(true, 2); else L(true, 4); }
-    else     { if (wpr == 1) L(false, 1); else if (wpr == 2) L(false, 2); else L(false, 4); }
-#undef L
+#define L3(R, W, M) VLLM_LAUNCH((norm_bf16_kernel<R, W, M>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
+#define L2(R, W) do { if (maxch == 1) L3(R, W, 1); else if (maxch == 2) L3(R, W, 2); else if (maxch == 4) L3(R, W, 4); else L3(R, W, 8); } while (0)
+    if (rms) { if (wpr == 1) L2(true, 1); else if (wpr == 2) L2(true, 2); else L2(true, 4); }
+    else     { if (wpr == 1) L2(false, 1); else if (wpr == 2) L2(false, 2); else L2(false, 4); }
+#undef L2
+#undef L3
     VLLM_CHECK_LAUNCH("norm_bf16_kernel");
     return VLLM_OK;
 }

@@ -1,6 +1,8 @@
 // Library-wide runtime helpers: ABI version, per-thread last error, device info.
 #include "common.hpp"
 #include <string.h>
+#include <stdlib.h>
+#include "kernels.hpp"
 
 namespace vllm {
 static thread_local char g_err[512] = "";
@@ -10,6 +12,16 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+int gemm_variant_override()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VLLM_GEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 2) v = 0;
+    }
+    return v;
 }
 }  // namespace vllm
 
