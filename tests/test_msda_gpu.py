@@ -96,6 +96,30 @@ def test_full_size_cfg4_vs_oracle_and_properties():
     torch.testing.assert_close(o, torch.full_like(o, 1.25), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["encoder_like", "wide_offsets", "odd_geometry"])
+def test_tiled_kernel_is_bit_identical_to_gather_kernel(mode):
+    """The LDS-tiled kernel (encoder shape: Lq == S, D=32, P=4) runs the same arithmetic as the gather kernel."""
+    from visionllm_amd import _lib
+    if mode == "odd_geometry":      # maps whose sizes are not multiples of the 8x16 query tile, 3 levels
+        shapes = [(61, 83), (31, 42), (9, 5)]
+        g = make_inputs(2, 8, 32, shapes, 4, mode="encoder_like", seed=4)
+    else:
+        g = make_inputs(2, 8, 32, CFG4_SHAPES, 4, mode="encoder_like", seed=1)
+    if mode == "wide_offsets":      # far-away samples: windows exceed the LDS budget -> per-level global fallback
+        rng = np.random.default_rng(0)
+        g["loc"] = (g["loc"] + rng.standard_normal(g["loc"].shape).astype(np.float32) * 0.2).astype(np.float32)
+    old = _lib.set_option("msda_tiled", 1)
+    try:
+        tiled = _run(g)
+        _lib.set_option("msda_tiled", 0)
+        plain = _run(g)
+    finally:
+        _lib.set_option("msda_tiled", old)
+    assert torch.equal(tiled, plain)
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
+    np.testing.assert_allclose(tiled.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
 def test_nonfinite_values_outside_the_footprint_do_not_leak():
     g = make_inputs(1, 2, 32, [(4, 4)], 4, Lq=16, mode="stress", seed=9)
     loc = np.full_like(g["loc"], 0.999)  # bottom-right pixel: only corner 1 in bounds

@@ -51,11 +51,13 @@ def main():
                     t[k] = t[k] + 0.01 * torch.randn_like(t[k])
             B, S, M, D = t["value"].shape
             Lq, L, P = t["loc"].shape[1], t["loc"].shape[3], t["loc"].shape[4]
-            for dt in ("f32", "bf16"):
-                v = t["value"] if dt == "f32" else t["value"].bfloat16()
+            for dt in ("f32", "f32_gather", "bf16"):
+                v = t["value"] if dt != "bf16" else t["value"].bfloat16()
+                from visionllm_amd import _lib
+                _lib.set_option("msda_tiled", 0 if dt == "f32_gather" else 1)
                 sec = timeit(lambda: A.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["attw"], 64), a.iters)
-                ab = algorithmic_bytes(B, S, M, D, L, Lq, P, 4 if dt == "f32" else 2)
-                gathered = B * Lq * M * L * P * 4 * D * (4 if dt == "f32" else 2)
+                ab = algorithmic_bytes(B, S, M, D, L, Lq, P, 4 if dt != "bf16" else 2)
+                gathered = B * Lq * M * L * P * 4 * D * (4 if dt != "bf16" else 2)
                 r = dict(mode=mode, dtype=dt, B=B, Lq=Lq, us=sec * 1e6, algo_GBs=ab / sec / 1e9,
                          frac_of_8TBs=ab / sec / 8e12, gathered_TBs=gathered / sec / 1e12)
                 res.append(r)

@@ -44,7 +44,9 @@ def parse_header(path: str = HEADER):
         if args and args != "void":
             for a in args.split(","):
                 a = a.strip()
-                if "*" in a:
+                if "char" in a and "*" in a:
+                    argtypes.append(ctypes.c_char_p)
+                elif "*" in a:
                     argtypes.append(ctypes.c_void_p)
                 else:
                     toks = [t for t in a.replace("const", " ").split() if t]
@@ -76,6 +78,11 @@ def lib():
         raise RuntimeError("libvllm_hip.so ABI version mismatch")
     _lib = L
     return L
+
+
+def set_option(name: str, value: int) -> int:
+    """Process-wide tuning / test knob (see include/vllm_hip.h: vllm_set_option)."""
+    return lib().vllm_set_option(name.encode(), int(value))
 
 
 def check(rc: int, what: str = ""):

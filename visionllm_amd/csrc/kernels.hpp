@@ -27,7 +27,8 @@ struct GemmArgs {
     int variant;            // 0 auto, 1 force 128x128 kernel, 2 force 256x256 8-phase kernel (tuning / tests)
 };
 
-int gemm_variant_override();   // reads VLLM_GEMM_VARIANT once (0/1/2)
+int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
+int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);
 

@@ -24,39 +24,13 @@
 // Roofline: HBM-bound on paper (11 flop/B); in practice limited by the 64 B/clk/CU vector-L1 path because the
 // gathered bytes are 18x the compulsory bytes (DESIGN.md section "MSDA").
 #include "common.hpp"
+#include "msda_sample.hpp"
 
 namespace vllm {
 
-// ---------------------------------------------------------------------------------------------------------
-// Integer part of one sampling point -- shared by every kernel so that "index-exact" is a property of ONE
-// function.  Mirrors ms_deform_im2col_cuda.cuh:277-292 and :38-41.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
-__device__ __forceinline__ float floor_t(float a) { return floorf(a); }
-__device__ __forceinline__ double floor_t(double a) { return floor(a); }
-
-template <typename T>
-struct SamplePoint {
-    T h_im, w_im;
-    int h_low, w_low;
-    bool ok;
-};
-
-template <typename T>
-__device__ __forceinline__ SamplePoint<T> sample_point(T loc_w, T loc_h, int H, int W)
-{
-    SamplePoint<T> s;
-    s.h_im = sub_rn(mul_rn(loc_h, (T)H), (T)0.5);
-    s.w_im = sub_rn(mul_rn(loc_w, (T)W), (T)0.5);
-    s.ok = (s.h_im > (T)-1) && (s.w_im > (T)-1) && (s.h_im < (T)H) && (s.w_im < (T)W);
-    // floor of a rejected (possibly NaN / huge) coordinate is never used for addressing un-clamped.
-    s.h_low = (int)floor_t(s.h_im);
-    s.w_low = (int)floor_t(s.w_im);
-    return s;
-}
+bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *out, const void *loc);
+int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                      const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------
 // Vectorised forward.
@@ -444,6 +418,8 @@ extern "C" int vllm_msda_forward_f32(const float *value, const int64_t *shapes, 
     if ((long)B * Lq == 0) return VLLM_OK;
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc))   // encoder self-attention shape: LDS-tiled kernel
+        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
     if (vec_ok(D, 4, L, P, value, out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0)
         return dispatch_vec<false>(D / 4, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
     return launch_generic_fwd<float>(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, st);

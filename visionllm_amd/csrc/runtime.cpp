@@ -13,18 +13,39 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static int g_gemm_variant = -1, g_msda_tiled = -1;
 int gemm_variant_override()
 {
-    static int v = -1;
-    if (v < 0) {
+    if (g_gemm_variant < 0) {
         const char *e = getenv("VLLM_GEMM_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 2) v = 0;
+        g_gemm_variant = e ? atoi(e) : 0;
+        if (g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 0;
     }
-    return v;
+    return g_gemm_variant;
+}
+int msda_tiled_enabled()
+{
+    if (g_msda_tiled < 0) {
+        const char *e = getenv("VLLM_MSDA_TILED");
+        g_msda_tiled = e ? (atoi(e) != 0) : 0;   // opt-in: measured slower than the gather kernel so far
+    }
+    return g_msda_tiled;
 }
 }  // namespace vllm
 
+extern "C" int vllm_set_option(const char *name, int value)
+{
+    if (!name) return VLLM_EINVAL;
+    if (!strcmp(name, "msda_tiled")) { const int old = vllm::msda_tiled_enabled(); vllm::g_msda_tiled = value != 0; return old; }
+    if (!strcmp(name, "gemm_variant")) {
+        const int old = vllm::gemm_variant_override();
+        if (value < 0 || value > 2) { vllm::set_error("gemm_variant must be 0..2"); return VLLM_EINVAL; }
+        vllm::g_gemm_variant = value;
+        return old;
+    }
+    vllm::set_error("unknown option %s", name);
+    return VLLM_EINVAL;
+}
 extern "C" int vllm_abi_version(void) { return VLLM_ABI_VERSION; }
 extern "C" const char *vllm_last_error(void) { return vllm::g_err; }
 extern "C" int vllm_device_info(char *name, int cap)
