@@ -164,6 +164,8 @@ def test_attention_online_softmax_rescale_branch(D):
     qkv = torch.randn(B, S, 3, H, D, device=DEV) * 0.5
     qkv[0, 200, 1, 0] = qkv[0, 10, 0, 0] * 8.0      # key 200 aligned with query 10 -> huge score in tile 3
     qkv[0, 3, 1, 1] = qkv[0, 150, 0, 1] * 8.0        # key 3 dominates from the first tile on
+    for j, key in enumerate(range(70, 300, 64)):     # max creeps up tile after tile by less than the defer threshold,
+        qkv[0, key, 1, 0] = qkv[0, 20, 0, 0] * (1.0 + 0.6 * j)   # then (cumulatively) by more -> deferred rescale path
     qkv = bf(qkv)
     out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
     _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))

@@ -90,24 +90,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
-
+    const float c2 = a.scale_log2e;
     const int nkt = (a.S + KVBLK - 1) / KVBLK;
-    stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane);
-    stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane);
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
 
-    for (int t = 0; t < nkt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // tile t landed for every wave; everyone is done reading the other stage
-        const char *ks_ = smem + (t & 1) * 2 * TILE;
-        const char *vs_ = ks_ + TILE;
-        if (t + 1 < nkt) {
-            char *nx = smem + ((t + 1) & 1) * 2 * TILE;
-            stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane);
-            stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane);
-        }
-
-        // ---- S^T = K Q^T : two 32-key blocks ----
-        f32x16_t st[2];
+    // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
+    auto qk = [&](const char *ks_, f32x16_t (&st)[2]) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -120,9 +109,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
+    };
 
-        // ---- online softmax (exp2 domain); lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31 ----
-        const int k0 = t * KVBLK;
+    // online softmax of one score tile (raw scores; scale*log2e folded into the exp2 argument) + O^T += V^T P^T.
+    // Lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31.  Rescale of O / l is DEFERRED while the running
+    // max grows by less than THR (exp2 domain): P is then bounded by 2^THR instead of 1 (fp32 accumulation).
+    auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0) {
+        constexpr float THR = 6.0f;
         float mx = -1.0e30f;
         if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
 #pragma unroll
@@ -130,42 +124,38 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float s2 = st[kb][r] * a.scale_log2e;
-                    st[kb][r] = key < a.S ? s2 : -1.0e30f;
-                    mx = fmaxf(mx, st[kb][r]);
-                }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[kb][r] *= a.scale_log2e;
-                    mx = fmaxf(mx, st[kb][r]);
+                    st[kb][r] = key < a.S ? st[kb][r] : -1.0e30f;
                 }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * c2;          // c2 > 0: max commutes with the scaling
+        if (!__all(mx - m_run <= THR)) {                    // wave-uniform; both halves of a query agree on mx
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
         float psum = 0.f;
         uint32_t pk[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
-                const float p1 = __builtin_amdgcn_exp2f(st[kb][r + 1] - m_new);
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -m_run));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c2, -m_run));
                 psum += p0 + p1;
                 pk[kb][r >> 1] = pack_bf16x2(p0, p1);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
-        // ---- O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11} ----
-        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+        l_run += psum;
+        // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -187,6 +177,34 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1].  K runs ONE tile ahead of V: iteration t computes the scores of
+    // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
+    auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
+    auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
+    stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane);
+    stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane);
+    if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16_t sA[2], sB[2];
+    qk(kslot(0), sA);
+
+    auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
+        // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
+        // slots of K_t / V_{t-1} that are refilled below (t = 0: the prologue's K_0 reads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane);
+        if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane);
+        if (t + 1 < nkt) qk(kslot(t + 1), nxt);
+        softmax_pv(cur, vslot(t), t * KVBLK);
+    };
+    for (int t = 0; t < nkt; t += 2) {
+        iteration(t, sA, sB);
+        if (t + 1 < nkt) iteration(t + 1, sB, sA);
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
