@@ -37,7 +37,8 @@ const char *vllm_last_error(void);
 int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": 1 lets the encoder-shaped MSDA forward use the LDS-tiled
  * kernel (bit-identical results; currently slower, so the default is 0 = plain gather kernel).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
- * kernel.  Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT give the initial values.  Returns the previous
+ * kernel.  "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters.
+ * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous
  * value or VLLM_EINVAL for an unknown name. */
 int vllm_set_option(const char *name, int value);
 

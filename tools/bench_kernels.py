@@ -59,6 +59,17 @@ def main():
                 r["torch_linear_us"] = sec2 * 1e6
                 r["torch_linear_TF"] = fl / sec2 / 1e12
             print(json.dumps(r), flush=True)
+    if "attnsweep" in what:
+        for name, B, S, H, D in [("vitl", a.tiles, 577, 16, 64), ("ivit6b_40", 40, 1025, 25, 128)]:
+            qkv = torch.randn(B, S, 3, H, D, device=dev).to(torch.bfloat16)
+            out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev)
+            f = lambda: _lib.check(L.vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, st))  # noqa: E731
+            fl = 4.0 * B * H * S * S * D
+            for rnd in range(2):
+                for var in range(8):
+                    _lib.set_option("attn_variant", var)
+                    sec = t(f, iters=10)
+                    print(json.dumps(dict(kernel="attn", name=name, variant=var, round=rnd, us=sec * 1e6, TF=fl / sec / 1e12)), flush=True)
     if "attn" in what:
         for name, B, S, H, D in [("vitl", a.tiles, 577, 16, 64), ("ivit6b", 5, 1025, 25, 128), ("ivit6b_40", 40, 1025, 25, 128)]:
             qkv = torch.randn(B, S, 3, H, D, device=dev).to(torch.bfloat16)

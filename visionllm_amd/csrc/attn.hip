@@ -54,9 +54,12 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
     }
 }
 
-template <int D>
+// VAR bit0: software-pipelined K (scores of tile t+1 next to the softmax of tile t); bit1: deferred rescale;
+// bit2: s_setprio(1) around the MFMA clusters.
+template <int D, int VAR>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs a)
 {
+    constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0;
     constexpr int KS = D / 16;            // k-steps of the QK^T product
     constexpr int DB = D / 32;            // 32-wide output blocks
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
 
     // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
     auto qk = [&](const char *ks_, f32x16_t (&st)[2]) {
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -109,14 +112,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // online softmax of one score tile (raw scores; scale*log2e folded into the exp2 argument) + O^T += V^T P^T.
     // Lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31.  Rescale of O / l is DEFERRED while the running
     // max grows by less than THR (exp2 domain): P is then bounded by 2^THR instead of 1 (fp32 accumulation).
     auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0) {
-        constexpr float THR = 6.0f;
+        constexpr float THR = DEFER ? 6.0f : 0.0f;
         float mx = -1.0e30f;
         if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * c2;          // c2 > 0: max commutes with the scaling
-        if (!__all(mx - m_run <= THR)) {                    // wave-uniform; both halves of a query agree on mx
+        if (!DEFER || !__all(mx - m_run <= THR)) {          // wave-uniform; both halves of a query agree on mx
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
             }
         l_run += psum;
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -177,34 +180,53 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1].  K runs ONE tile ahead of V: iteration t computes the scores of
-    // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
-    auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
-    auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
-    stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane);
-    stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane);
-    if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    f32x16_t sA[2], sB[2];
-    qk(kslot(0), sA);
-
-    auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
-        // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
-        // slots of K_t / V_{t-1} that are refilled below (t = 0: the prologue's K_0 reads)
+    if constexpr (PIPE) {
+        // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1].  K runs ONE tile ahead of V: iteration t computes the scores of
+        // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
+        auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
+        auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
+        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane);
+        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane);
+        if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane);
-        if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane);
-        if (t + 1 < nkt) qk(kslot(t + 1), nxt);
-        softmax_pv(cur, vslot(t), t * KVBLK);
-    };
-    for (int t = 0; t < nkt; t += 2) {
-        iteration(t, sA, sB);
-        if (t + 1 < nkt) iteration(t + 1, sB, sA);
+        f32x16_t sA[2], sB[2];
+        qk(kslot(0), sA);
+
+        auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
+            // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
+            // slots of K_t / V_{t-1} that are refilled below (t = 0: the prologue's K_0 reads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane);
+            if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane);
+            if (t + 1 < nkt) qk(kslot(t + 1), nxt);
+            softmax_pv(cur, vslot(t), t * KVBLK);
+        };
+        for (int t = 0; t < nkt; t += 2) {
+            iteration(t, sA, sB);
+            if (t + 1 < nkt) iteration(t + 1, sB, sA);
+        }
+    } else {
+        // plain schedule: K_t and V_t staged together one tile ahead; QK -> softmax -> PV in sequence
+        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane);
+        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane);
+        for (int t = 0; t < nkt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // tile t landed for every wave; everyone is done reading the other stage
+            const char *ks_ = smem + (t & 1) * 2 * TILE;
+            if (t + 1 < nkt) {
+                char *nx = smem + ((t + 1) & 1) * 2 * TILE;
+                stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane);
+                stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane);
+            }
+            f32x16_t st[2];
+            qk(ks_, st);
+            softmax_pv(st, ks_ + TILE, t * KVBLK);
+        }
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
@@ -238,8 +260,13 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64>), grid, block, lds, st, a);
-    else VLLM_LAUNCH((attn_fwd_kernel<128>), grid, block, lds, st, a);
+    const int var = attn_variant() & 7;
+#define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
+#define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 1: LA(DD, 1); break; case 2: LA(DD, 2); break; \
+    case 3: LA(DD, 3); break; case 4: LA(DD, 4); break; case 5: LA(DD, 5); break; case 6: LA(DD, 6); break; default: LA(DD, 7); } } while (0)
+    if (D == 64) LV(64); else LV(128);
+#undef LV
+#undef LA
     VLLM_CHECK_LAUNCH("attn_fwd_kernel");
     return VLLM_OK;
 }

@@ -28,6 +28,7 @@ struct GemmArgs {
 };
 
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
+int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);

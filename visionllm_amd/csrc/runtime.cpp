@@ -13,7 +13,15 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static int g_gemm_variant = -1, g_msda_tiled = -1;
+static int g_gemm_variant = -1, g_msda_tiled = -1, g_attn_variant = -1;
+int attn_variant()
+{
+    if (g_attn_variant < 0) {
+        const char *e = getenv("VLLM_ATTN_VARIANT");
+        g_attn_variant = e ? (atoi(e) & 7) : 2;
+    }
+    return g_attn_variant;
+}
 int gemm_variant_override()
 {
     if (g_gemm_variant < 0) {
@@ -37,6 +45,7 @@ extern "C" int vllm_set_option(const char *name, int value)
 {
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) { const int old = vllm::msda_tiled_enabled(); vllm::g_msda_tiled = value != 0; return old; }
+    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 7; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
         if (value < 0 || value > 2) { vllm::set_error("gemm_variant must be 0..2"); return VLLM_EINVAL; }
