@@ -76,7 +76,9 @@ def test_full_size_cfg4_vs_oracle_and_properties():
     g = make_inputs(2, 8, 32, CFG4_SHAPES, 4, mode="encoder_like", seed=0)
     out = _run(g)
     ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    # tight: a fused loc*H-0.5 (one rounding instead of the reference's two) shows up as ~1e-5 wherever loc*H crosses
+    # a power of two (regression test for the backend-contraction bug found on hardware)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=4e-6, atol=4e-6)
     h, w, mk = A.sample_index(_t(g["shapes"]), _t(g["loc"]))
     ho, wo, mo = O.sample_index(g["shapes"], g["loc"])
     assert np.array_equal(mk.cpu().numpy(), mo) and np.array_equal(h.cpu().numpy(), ho) \
@@ -97,7 +99,7 @@ def test_full_size_cfg4_vs_oracle_and_properties():
 
 
 @pytest.mark.parametrize("mode", ["encoder_like", "wide_offsets", "odd_geometry"])
-def test_tiled_kernel_is_bit_identical_to_gather_kernel(mode):
+def test_tiled_kernel_matches_gather_kernel(mode):
     """The LDS-tiled kernel (encoder shape: Lq == S, D=32, P=4) runs the same arithmetic as the gather kernel."""
     from visionllm_amd import _lib
     if mode == "odd_geometry":      # maps whose sizes are not multiples of the 8x16 query tile, 3 levels
@@ -115,9 +117,10 @@ def test_tiled_kernel_is_bit_identical_to_gather_kernel(mode):
         plain = _run(g)
     finally:
         _lib.set_option("msda_tiled", old)
-    assert torch.equal(tiled, plain)
+    # same arithmetic per (query, point); only the compiler's contraction choices may differ between the two kernels
+    torch.testing.assert_close(tiled, plain, rtol=2e-6, atol=2e-6)
     ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-    np.testing.assert_allclose(tiled.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tiled.cpu().numpy(), ref, rtol=4e-6, atol=4e-6)
 
 
 def test_nonfinite_values_outside_the_footprint_do_not_leak():
@@ -129,6 +132,26 @@ def test_nonfinite_values_outside_the_footprint_do_not_leak():
     assert torch.isfinite(o).all()
     ref = O.forward(v, g["shapes"], g["lsi"], loc, g["attw"])
     np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_nan_and_inf_sampling_locations_contribute_nothing():
+    """Reference: the acceptance test is false for NaN / +-inf coordinates, so such points are skipped."""
+    from visionllm_amd import _lib
+    g = make_inputs(1, 8, 32, [(24, 32), (12, 16)], 4, mode="encoder_like", seed=6)
+    loc = g["loc"].copy()
+    flat = loc.reshape(-1)
+    flat[5::37] = np.nan
+    flat[11::53] = np.inf
+    flat[12::59] = -np.inf
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], loc, g["attw"])
+    assert np.isfinite(ref).all()
+    for tiled in (0, 1):
+        old = _lib.set_option("msda_tiled", tiled)
+        try:
+            out = A.ms_deform_attn_forward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]), 64)
+        finally:
+            _lib.set_option("msda_tiled", old)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
 def test_edge_cases_and_errors():

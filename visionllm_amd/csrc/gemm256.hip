@@ -204,7 +204,7 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     const size_t lds = 2 * G2_STAGE;   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-#define SETATTR(E) hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SETATTR(EPI_BIAS); SETATTR(EPI_GELU); SETATTR(EPI_QUICK_GELU); SETATTR(EPI_RESIDUAL); SETATTR(EPI_EMBED);
 #undef SETATTR
         attr_set = true;

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
                 const int hl = sp.h_low, wl = sp.w_low;
                 const float lh = sp.h_im - (float)hl, lw = sp.w_im - (float)wl;
                 const float hh = 1.f - lh, hw = 1.f - lw;
-                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                // a rejected point (incl. NaN / inf locations) contributes exactly nothing, as in the reference
+                const float w1 = sp.ok ? hh * hw : 0.f, w2 = sp.ok ? hh * lw : 0.f;
+                const float w3 = sp.ok ? lh * hw : 0.f, w4 = sp.ok ? lh * lw : 0.f;
                 const bool k1 = sp.ok && hl >= 0 && wl >= 0;
                 const bool k2 = sp.ok && hl >= 0 && wl + 1 <= W - 1;
                 const bool k3 = sp.ok && hl + 1 <= H - 1 && wl >= 0;

@@ -8,10 +8,24 @@ namespace vllm {
 // Integer part of one sampling point -- shared by every kernel so that "index-exact" is a property of ONE
 // function.  Mirrors ms_deform_im2col_cuda.cuh:277-292 and :38-41.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+// HIP's __fmul_rn / __fsub_rn are plain operators, and under the default -ffp-contract=fast the BACKEND fuses
+// mul + sub into one fma whatever the source says (found on hardware: 1-2 ulp different h_im where loc*H crosses a
+// power of two; `#pragma clang fp contract(off)` does not stop it).  The reference rounds twice and floor() of this
+// value is the index-exact part of the contract, so the product is made opaque to the optimiser (zero instructions).
+__device__ __forceinline__ float mul_rn(float a, float b)
+{
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ double mul_rn(double a, double b)
+{
+    double p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ double sub_rn(double a, double b) { return a - b; }
 __device__ __forceinline__ float floor_t(float a) { return floorf(a); }
 __device__ __forceinline__ double floor_t(double a) { return floor(a); }
 
@@ -29,9 +43,10 @@ __device__ __forceinline__ SamplePoint<T> sample_point(T loc_w, T loc_h, int H, 
     s.h_im = sub_rn(mul_rn(loc_h, (T)H), (T)0.5);
     s.w_im = sub_rn(mul_rn(loc_w, (T)W), (T)0.5);
     s.ok = (s.h_im > (T)-1) && (s.w_im > (T)-1) && (s.h_im < (T)H) && (s.w_im < (T)W);
-    // floor of a rejected (possibly NaN / huge) coordinate is never used for addressing un-clamped.
-    s.h_low = (int)floor_t(s.h_im);
-    s.w_low = (int)floor_t(s.w_im);
+    // accepted coordinates lie in (-1, H) x (-1, W): their floor is in [-1, H-1].  A rejected coordinate may be NaN,
+    // +-inf or huge; its float->int conversion (and the +1 that follows) must never reach address arithmetic.
+    s.h_low = s.ok ? (int)floor_t(s.h_im) : 0;
+    s.w_low = s.ok ? (int)floor_t(s.w_im) : 0;
     return s;
 }
 

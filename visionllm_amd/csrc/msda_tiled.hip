@@ -25,52 +25,54 @@ constexpr int MT_THREADS = 256;
 constexpr int MT_NQ = MT_TH * MT_TW;             // 128 queries per block
 constexpr int MT_QPP = MT_THREADS / 8;           // 32 queries per pass (8 lanes x 16 B = D 32 fp32)
 constexpr int MT_NPASS = MT_NQ / MT_QPP;         // 4
-constexpr int MT_WIN_MAX = 504;                  // window budget in pixels (x 128 B) -> 2 blocks per CU
+constexpr int MT_WIN_MAX = 560;                  // window budget in pixels (x 128 B); 2 blocks per CU
+constexpr int MT_ZP = MT_WIN_MAX + 8;            // index of the all-zero pixel (behind the LDS-DMA slack)
 constexpr int MT_MAXL = 8;
+constexpr size_t MT_LDS_WIN = (size_t)(MT_ZP + 1) * 128;
+constexpr size_t MT_LDS_LOC = MT_NQ * 4 * 8, MT_LDS_AW = MT_NQ * 4 * 4;   // per-level loc (float2) / weights
+constexpr size_t MT_LDS = MT_LDS_WIN + MT_LDS_LOC + MT_LDS_AW;
 
+template <int K>
+__device__ __forceinline__ float quad_bcast(float x)   // value of lane K of this lane's quad
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false);
+}
 
-template <int PT, bool LDS>
-__device__ __forceinline__ void gather_level(float (&acc)[MT_NPASS][4], const long (&qidx)[MT_NPASS],
-                                             const bool (&qok)[MT_NPASS], const float *__restrict__ loc,
-                                             const float *__restrict__ attw, int l, int L, int H, int W,
-                                             const float *__restrict__ vl, long MD, const float *wb, int y0, int y1,
-                                             int x0w, int x1w, int ww)
+// Global-memory fallback for one (block, level) whose window exceeds the LDS budget: the gather kernel's code,
+// with loc / weights read from the LDS copy.
+template <int PT>
+__device__ __forceinline__ void gather_level_global(float (&acc)[MT_NPASS][4], const bool (&qok)[MT_NPASS],
+                                                    const float2_t *s_loc, const float *s_aw, int slot0, int H, int W,
+                                                    const float *__restrict__ vl, long MD)
 {
 #pragma unroll
     for (int p = 0; p < MT_NPASS; ++p) {
-        const float *lp = loc + (qidx[p] * L + l) * (PT * 2);
-        const float *wp = attw + qidx[p] * L * PT + l * PT;
+        const int slot = p * MT_QPP + slot0;
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
-            const float2_t xy = *reinterpret_cast<const float2_t *>(lp + 2 * k);
-            const float aw = wp[k];
+            const float2_t xy = s_loc[slot * PT + k];
+            const float aw = s_aw[slot * PT + k];
             const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
             const int hl = sp.h_low, wl = sp.w_low;
             const float lh = sp.h_im - (float)hl, lw = sp.w_im - (float)wl;
             const float hh = 1.f - lh, hw = 1.f - lw;
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
             const bool pok = sp.ok && qok[p];
+            const float w1 = pok ? hh * hw : 0.f, w2 = pok ? hh * lw : 0.f, w3 = pok ? lh * hw : 0.f, w4 = pok ? lh * lw : 0.f;
             const bool k1 = pok && hl >= 0 && wl >= 0;
             const bool k2 = pok && hl >= 0 && wl + 1 <= W - 1;
             const bool k3 = pok && hl + 1 <= H - 1 && wl >= 0;
             const bool k4 = pok && hl + 1 <= H - 1 && wl + 1 <= W - 1;
-            int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
-            int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);
-            float4_t v1, v2, v3, v4;
-            if (LDS) {
-                // rejected points / dead queries may lie outside the window: clamp INTO it (values never used)
-                h0 = min(max(h0, y0), y1) - y0; h1 = min(max(h1, y0), y1) - y0;
-                x0 = min(max(x0, x0w), x1w) - x0w; x1 = min(max(x1, x0w), x1w) - x0w;
-                v1 = *reinterpret_cast<const float4_t *>(wb + (h0 * ww + x0) * 32);
-                v2 = *reinterpret_cast<const float4_t *>(wb + (h0 * ww + x1) * 32);
-                v3 = *reinterpret_cast<const float4_t *>(wb + (h1 * ww + x0) * 32);
-                v4 = *reinterpret_cast<const float4_t *>(wb + (h1 * ww + x1) * 32);
-            } else {
-                v1 = *reinterpret_cast<const float4_t *>(vl + ((long)h0 * W + x0) * MD);
-                v2 = *reinterpret_cast<const float4_t *>(vl + ((long)h0 * W + x1) * MD);
-                v3 = *reinterpret_cast<const float4_t *>(vl + ((long)h1 * W + x0) * MD);
-                v4 = *reinterpret_cast<const float4_t *>(vl + ((long)h1 * W + x1) * MD);
-            }
+            const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
+            const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);
+            const float4_t v1 = *reinterpret_cast<const float4_t *>(vl + ((long)h0 * W + x0) * MD);
+            const float4_t v2 = *reinterpret_cast<const float4_t *>(vl + ((long)h0 * W + x1) * MD);
+            const float4_t v3 = *reinterpret_cast<const float4_t *>(vl + ((long)h1 * W + x0) * MD);
+            const float4_t v4 = *reinterpret_cast<const float4_t *>(vl + ((long)h1 * W + x1) * MD);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float a1 = k1 ? v1[c] : 0.f, a2 = k2 ? v2[c] : 0.f;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void gather_level(float (&acc)[MT_NPASS][4], const lo
                 acc[p][c] += val * aw;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // one query pass at a time: bounds the loads in flight / VGPRs
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -89,9 +91,12 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
     float *__restrict__ out)
 {
+    static_assert(PT == 4, "one sampling point per lane of a quad");
     constexpr int D = 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [(MT_WIN_MAX + 8) pixels][128 B]
-    float *win = reinterpret_cast<float *>(smem);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *win = reinterpret_cast<float *>(smem);                               // [(MT_ZP + 1) pixels][32]
+    float2_t *s_loc = reinterpret_cast<float2_t *>(smem + MT_LDS_WIN);            // [128 queries][4 points]
+    float *s_aw = reinterpret_cast<float *>(smem + MT_LDS_WIN + MT_LDS_LOC);      // [128 queries][4 points]
     __shared__ int s_H[MT_MAXL], s_W[MT_MAXL], s_q0[MT_MAXL], s_tc[MT_MAXL + 1];
     __shared__ long s_v0[MT_MAXL];
     __shared__ int s_red[4][4];
@@ -99,9 +104,11 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int sub = tid & 7;                     // 16-byte channel chunk of this lane
+    const int kpt = tid & 3;                     // the sampling point this lane evaluates for its quad
+    const int slot0 = tid >> 3;                  // query slot inside a pass
     const long MD = (long)M * D;
 
-    // ---- tile table from the device-side shapes ----
+    // ---- tile table from the device-side shapes; zero pixel ----
     if (tid == 0) {
         long cum = 0;
         int tc = 0;
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
         s_tc[L] = tc;
         s_geo_ok = (cum == (long)Lq);
     }
+    if (tid < 32) win[MT_ZP * 32 + tid] = 0.f;
     __syncthreads();
-    // queries are tiled on the pyramid geometry when it matches Lq; otherwise as one 1 x Lq strip (still exact)
     const bool geo = s_geo_ok != 0;
     const int n_tiles = geo ? s_tc[L] : (Lq + MT_TW - 1) / MT_TW;
     const long n_items = (long)B * M * n_tiles;
@@ -141,42 +148,65 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
         } else {
             qH = 1; qW = Lq; q0 = 0; ty = 0; tx = t;
         }
+        // (b, q, m) pair index of tile slot s (clamped to a live query) and whether the slot is live
+        auto pair_of = [&](int slot, bool &ok) -> long {
+            const int y = ty * MT_TH + slot / MT_TW, x = tx * MT_TW + slot % MT_TW;
+            ok = y < qH && x < qW;
+            const long q = q0 + (long)(ok ? y : 0) * qW + (ok ? x : 0);
+            return (b * Lq + q) * M + m;
+        };
 
-        // my queries (one per pass)
         long qidx[MT_NPASS];
         bool qok[MT_NPASS];
         float acc[MT_NPASS][4];
 #pragma unroll
         for (int p = 0; p < MT_NPASS; ++p) {
-            const int slot = p * MT_QPP + (tid >> 3);
-            const int y = ty * MT_TH + slot / MT_TW, x = tx * MT_TW + slot % MT_TW;
-            qok[p] = y < qH && x < qW;
-            const long q = q0 + (long)(qok[p] ? y : 0) * qW + (qok[p] ? x : 0);
-            qidx[p] = (b * Lq + q) * M + m;   // (b, q, m) pair index
+            qidx[p] = pair_of(p * MT_QPP + slot0, qok[p]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
         }
+        // cooperative loc / weight loads: thread i -> query slot i>>1, points 2*(i&1).. ; weights: threads < 128
+        bool lq_ok, aq_ok;
+        const long lq_pair = pair_of(tid >> 1, lq_ok);
+        const long aq_pair = pair_of(tid & (MT_NQ - 1), aq_ok);
+
+        // loc / weights of level l+1 are fetched into registers while level l is processed (the global latency would
+        // otherwise be exposed twice per level: once here, once for the window)
+        float4_t nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + 0) * (PT * 2) + (tid & 1) * 4);
+        float4_t naw = {0.f, 0.f, 0.f, 0.f};
+        if (tid < MT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + 0) * PT);
 
         for (int l = 0; l < L; ++l) {
             const int H = s_H[l], W = s_W[l];
             const float *vl = value + (b * (long)S + s_v0[l]) * MD + (long)m * D + sub * 4;
 
-            // ---- A: exact bounding window of every corner this block will touch at level l ----
+            __syncthreads();   // previous level / item: every read of s_loc, s_aw, win, s_red is finished
+            reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
+            if (tid < MT_NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
+            if (l + 1 < L) {
+                nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l + 1) * (PT * 2) + (tid & 1) * 4);
+                if (tid < MT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l + 1) * PT);
+            }
+            __syncthreads();
+
+            // ---- A: this lane's point (kpt) of each of its 4 queries; exact bounding window of all corners ----
+            float him[MT_NPASS], wim[MT_NPASS], awp[MT_NPASS];
+            int hlo[MT_NPASS], wlo[MT_NPASS];
+            bool okp[MT_NPASS];
             int ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1;
 #pragma unroll
             for (int p = 0; p < MT_NPASS; ++p) {
-                const float *lp = loc + (qidx[p] * L + l) * (PT * 2);
-#pragma unroll
-                for (int k = 0; k < PT; ++k) {
-                    const float2_t xy = *reinterpret_cast<const float2_t *>(lp + 2 * k);
-                    const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
-                    if (qok[p] && sp.ok) {
-                        const int h0 = min(max(sp.h_low, 0), H - 1), h1 = min(max(sp.h_low + 1, 0), H - 1);
-                        const int x0 = min(max(sp.w_low, 0), W - 1), x1 = min(max(sp.w_low + 1, 0), W - 1);
-                        ymin = min(ymin, h0); ymax = max(ymax, h1); xmin = min(xmin, x0); xmax = max(xmax, x1);
-                    }
+                const int slot = p * MT_QPP + slot0;
+                const float2_t xy = s_loc[slot * PT + kpt];
+                awp[p] = s_aw[slot * PT + kpt];
+                const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
+                him[p] = sp.h_im; wim[p] = sp.w_im; hlo[p] = sp.h_low; wlo[p] = sp.w_low;
+                okp[p] = sp.ok && qok[p];
+                if (okp[p]) {
+                    const int h0 = min(max(sp.h_low, 0), H - 1), h1 = min(max(sp.h_low + 1, 0), H - 1);
+                    const int x0 = min(max(sp.w_low, 0), W - 1), x1 = min(max(sp.w_low + 1, 0), W - 1);
+                    ymin = min(ymin, h0); ymax = max(ymax, h1); xmin = min(xmin, x0); xmax = max(xmax, x1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             int r0 = ymin, r1 = -ymax, r2 = xmin, r3 = -xmax;   // four min-reductions
 #pragma unroll
@@ -184,7 +214,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
                 r0 = min(r0, __shfl_xor(r0, o)); r1 = min(r1, __shfl_xor(r1, o));
                 r2 = min(r2, __shfl_xor(r2, o)); r3 = min(r3, __shfl_xor(r3, o));
             }
-            __syncthreads();   // previous level's window reads (and s_red reads) are finished
             if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
             __syncthreads();
             const int y0 = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
@@ -194,28 +223,65 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
             if (y1 < 0) continue;                        // no accepted point at this level (block-uniform)
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
-            const bool use_lds = npix <= MT_WIN_MAX;     // block-uniform
-
-            // ---- B: stage the window (LDS-DMA, 8 pixels of 128 B per wave instruction) ----
-            if (use_lds) {
-                for (int i0 = wave * 8; i0 < npix; i0 += 32) {
-                    int pix = i0 + (lane >> 3);
-                    pix = pix < npix ? pix : npix - 1;
-                    const int wy = pix / ww, wx = pix - wy * ww;
-                    const float *g = vl + ((long)(y0 + wy) * W + (x0w + wx)) * MD;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                     (__attribute__((address_space(3))) void *)(win + i0 * 32), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+            if (npix > MT_WIN_MAX) {                     // block-uniform: window does not fit -> gather from global
+                gather_level_global<PT>(acc, qok, s_loc, s_aw, slot0, H, W, vl, MD);
+                continue;
             }
 
-            // ---- C: gather + accumulate (same arithmetic as msda_fwd_vec_kernel).  Two separate code bodies
-            // (window in LDS / global fallback) keep the register pressure of each bounded. ----
-            if (use_lds)
-                gather_level<PT, true>(acc, qidx, qok, loc, attw, l, L, H, W, vl, MD, win + sub * 4, y0, y1, x0w, x1w, ww);
-            else
-                gather_level<PT, false>(acc, qidx, qok, loc, attw, l, L, H, W, vl, MD, win + sub * 4, y0, y1, x0w, x1w, ww);
+            // ---- B: stage the window (LDS-DMA, 8 pixels of 128 B per wave instruction) ----
+            for (int i0 = wave * 8; i0 < npix; i0 += 32) {
+                int pix = i0 + (lane >> 3);
+                pix = pix < npix ? pix : npix - 1;
+                const int wy = pix / ww, wx = pix - wy * ww;
+                const float *g = vl + ((long)(y0 + wy) * W + (x0w + wx)) * MD;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(win + i0 * 32), 16, 0, 0);
+            }
+            // the owner lane turns its point into 4 LDS byte offsets (+ this lane's channel chunk) and 4 weights while
+            // the DMA is in flight; a corner that must not contribute points at the all-zero pixel
+            int o1[MT_NPASS], o2[MT_NPASS], o3[MT_NPASS], o4[MT_NPASS];
+            float w1[MT_NPASS], w2[MT_NPASS], w3[MT_NPASS], w4[MT_NPASS];
+#pragma unroll
+            for (int p = 0; p < MT_NPASS; ++p) {
+                const int hl = hlo[p], wl = wlo[p];
+                const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool pok = okp[p];
+                w1[p] = pok ? hh * hw : 0.f; w2[p] = pok ? hh * lw : 0.f;
+                w3[p] = pok ? lh * hw : 0.f; w4[p] = pok ? lh * lw : 0.f;
+                const bool k1 = pok && hl >= 0 && wl >= 0;
+                const bool k2 = pok && hl >= 0 && wl + 1 <= W - 1;
+                const bool k3 = pok && hl + 1 <= H - 1 && wl >= 0;
+                const bool k4 = pok && hl + 1 <= H - 1 && wl + 1 <= W - 1;
+                const int ry0 = hl - y0, ry1 = hl + 1 - y0, rx0 = wl - x0w, rx1 = wl + 1 - x0w;
+                o1[p] = (k1 ? ry0 * ww + rx0 : MT_ZP) * 128;
+                o2[p] = (k2 ? ry0 * ww + rx1 : MT_ZP) * 128;
+                o3[p] = (k3 ? ry1 * ww + rx0 : MT_ZP) * 128;
+                o4[p] = (k4 ? ry1 * ww + rx1 : MT_ZP) * 128;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            // ---- C: gather from LDS; the quad's lane K broadcasts point K's offsets / weights (DPP) ----
+            const char *wbase = reinterpret_cast<const char *>(win) + sub * 16;
+#define MT_POINT(K)                                                                                              \
+    {                                                                                                            \
+        const float4_t v1 = *reinterpret_cast<const float4_t *>(wbase + quad_bcast<K>(o1[p]));                   \
+        const float4_t v2 = *reinterpret_cast<const float4_t *>(wbase + quad_bcast<K>(o2[p]));                   \
+        const float4_t v3 = *reinterpret_cast<const float4_t *>(wbase + quad_bcast<K>(o3[p]));                   \
+        const float4_t v4 = *reinterpret_cast<const float4_t *>(wbase + quad_bcast<K>(o4[p]));                   \
+        const float b1 = quad_bcast<K>(w1[p]), b2 = quad_bcast<K>(w2[p]), b3 = quad_bcast<K>(w3[p]),             \
+                    b4 = quad_bcast<K>(w4[p]), ba = quad_bcast<K>(awp[p]);                                       \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+            const float val = b1 * v1[c] + b2 * v2[c] + b3 * v3[c] + b4 * v4[c];                                 \
+            acc[p][c] += val * ba;                                                                               \
+        }                                                                                                        \
+    }
+#pragma unroll
+            for (int p = 0; p < MT_NPASS; ++p) {
+                MT_POINT(0) MT_POINT(1) MT_POINT(2) MT_POINT(3)
+            }
+#undef MT_POINT
         }
 #pragma unroll
         for (int p = 0; p < MT_NPASS; ++p)
@@ -223,7 +289,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
                 float4_t o = {acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
                 *reinterpret_cast<float4_t *>(out + qidx[p] * D + sub * 4) = o;
             }
-        __syncthreads();   // the next item's first staging must not overwrite a window still being read
     }
 }
 
@@ -243,10 +308,10 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    const size_t lds = (size_t)(MT_WIN_MAX + 8) * 128;
+    const size_t lds = MT_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU

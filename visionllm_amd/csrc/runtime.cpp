@@ -35,7 +35,7 @@ int msda_tiled_enabled()
 {
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
-        g_msda_tiled = e ? (atoi(e) != 0) : 0;   // opt-in: measured slower than the gather kernel so far
+        g_msda_tiled = e ? (atoi(e) != 0) : 1;
     }
     return g_msda_tiled;
 }
