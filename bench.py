@@ -38,9 +38,26 @@ IMAGES_PER_RANK = 8
 TILES_PER_IMAGE = 5
 VIT = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=24, image_size=336,
            patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+# BASELINE.json configs[2]: InternViT-6B + pixel-shuffle + internvl_mlp projector on 448x448 tiles (--workload internvit6b)
+IVIT = dict(hidden_size=3200, num_attention_heads=25, intermediate_size=12800, num_hidden_layers=48, image_size=448,
+            patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu", layer_norm_eps=1e-6)
 LLM_HIDDEN = 4096
 MSDA = dict(M=8, D=32, P=4, shapes=[(168, 168), (84, 84), (42, 42), (21, 21)], dec_queries=900, enc_layers=6,
             dec_layers=6)
+
+
+def build_intern_model(dev):
+    from visionllm_amd.bridge import build_vl_bridge
+    from visionllm_amd.intern_vit import InternVisionConfig, InternVisionModel
+    torch.manual_seed(0)
+    with torch.device(dev):
+        enc = InternVisionModel(InternVisionConfig(**IVIT))
+        with torch.no_grad():
+            for name, p in enc.named_parameters():
+                if p.dim() >= 2:
+                    p.normal_(0, 0.02)
+        bridge = build_vl_bridge("internvl_mlp", IVIT["hidden_size"], LLM_HIDDEN, use_pixelshuffle=True)
+    return enc.to(torch.bfloat16).eval(), bridge.to(torch.bfloat16).eval()
 
 
 def build_model(dev):
@@ -109,7 +126,7 @@ def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     ab = msda_bytes(t)
-    out["msda"] = dict(kernel="msda_fwd_vec_kernel<fp32,D32,P4>", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
+    out["msda"] = dict(kernel="msda_fwd_tiled_kernel<P4> (fp32, D32, encoder shape Lq=S=37485, B=8)", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
                        unit="GB/s", frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6,
                        algorithmic_bytes=ab)
     # (2) attention kernel: MFMA bound, flops = 4*H*S^2*d per tile
@@ -119,7 +136,7 @@ def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     fl = 4.0 * H * S * S * D * n_tiles
-    out["attn"] = dict(kernel="attn_fwd_kernel<64>", bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF,
+    out["attn"] = dict(kernel="attn_fwd_kernel<D64> (ViT-L: 40 tiles x 16 heads x S577)", bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF,
                        unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None, us_per_launch=sec * 1e6,
                        algorithmic_flops=fl)
     # (3) the dominant GEMM (MLP fc1: [M,1024] x [4096,1024]^T + bias + quick_gelu)
@@ -132,7 +149,7 @@ def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     fl = 2.0 * M * I * C
-    out["gemm"] = dict(kernel="gemm_bf16_kernel<quick_gelu> fc1", bound="mfma", achieved=fl / sec / 1e12,
+    out["gemm"] = dict(kernel="gemm256_bf16_kernel<quick_gelu> (MLP fc1: M23080 N4096 K1024)", bound="mfma", achieved=fl / sec / 1e12,
                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None,
                        us_per_launch=sec * 1e6, algorithmic_flops=fl)
     # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
@@ -211,6 +228,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="vitl", choices=["vitl", "internvit6b"],
+                    help="vitl (default; the metric's ViT-L config) or internvit6b (BASELINE configs[2]: 5 tiles of 448^2 per "
+                         "image through InternViT-6B + pixel-shuffle + internvl_mlp projector)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -229,15 +249,19 @@ def main():
     from visionllm_amd import ms_deform_attn as A
     from visionllm_amd.dist import all_gather_visual_tokens
 
-    enc, bridge = build_model(dev)
+    ivit = args.workload == "internvit6b"
+    enc, bridge = build_intern_model(dev) if ivit else build_model(dev)
+    if ivit:
+        enc.keep_hidden_states = (-1, -2, -3)   # 49 x 262 MB otherwise; the reference reads only these
     n_tiles = IMAGES_PER_RANK * TILES_PER_IMAGE
+    img = IVIT["image_size"] if ivit else VIT["image_size"]
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    pixels = torch.randn(n_tiles, 3, VIT["image_size"], VIT["image_size"], device=dev, generator=gen).to(torch.bfloat16)
+    pixels = torch.randn(n_tiles, 3, img, img, device=dev, generator=gen).to(torch.bfloat16)
     msda_in = build_msda_inputs(dev, IMAGES_PER_RANK, 200 + rank)
 
     def step():
         out = enc(pixels, output_hidden_states=True)
-        tokens = bridge.project_hidden_state(out.hidden_states[-2], False)
+        tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
         gathered, _ = all_gather_visual_tokens(tokens)
         res = [gathered]
         for tag, n in (("enc", MSDA["enc_layers"]), ("dec", MSDA["dec_layers"])):
@@ -266,7 +290,7 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        rl = kernel_rooflines(dev, enc, msda_in, n_tiles)
+        rl = kernel_rooflines(dev, enc, msda_in, IMAGES_PER_RANK * TILES_PER_IMAGE)
         # dominant kernel by time share of a step: the GEMM family (~85 % of the ViT FLOPs)
         line = {
             "metric": "images/sec (ViT-L+projector+MSDeformAttn fwd, 1336px)",
@@ -281,14 +305,16 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4", "images_per_gpu": IMAGES_PER_RANK,
-                       "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336", "vit": "ViT-L/14-336 24L bf16",
-                       "bridge": "mlp2x_gelu 1024->4096->4096", "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
+            "config": {"workload": ("internvit6b_448_5tiles+pixelshuffle+internvl_mlp+msda_cfg4" if ivit else
+                                    "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4"), "images_per_gpu": IMAGES_PER_RANK,
+                       "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336",
+                       "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
+                       "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096", "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
                        "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else "")},
             "roofline": {k: rl["gemm"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": rl["gemm"]["kernel"]},
             "rooflines": rl,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not ivit:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/pmc_traffic.json (HBM bytes per launch).
+
+Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes of a
+wide coalesced read stream, so reads are doubled; both counters are in KiB.  Gather-heavy kernels (MSDA) are not a wide
+coalesced stream, so their figure is an upper-bound style estimate and is flagged as such."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KEY = {"msda_fwd": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<2>": "gemm", "gemm256_bf16_kernelILi2": "gemm"}
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for path in f:
+        for r in csv.DictReader(open(path)):
+            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(fetch_dir, write_dir, out):
+    res = {}
+    raw = {}
+    for d in (fetch_dir, write_dir):
+        for (kn, cn), vals in load(d).items():
+            for pat, key in KEY.items():
+                if pat in kn:
+                    vals = sorted(vals)
+                    raw.setdefault(key, {})[cn] = vals[len(vals) // 2]   # median launch
+    for key, c in raw.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res[key] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    json.dump(res, open(out, "w"), indent=1)
+    json.dump(raw, open(out.replace(".json", "_raw.json"), "w"), indent=1)
+    print(json.dumps({"traffic_bytes_per_launch": res, "raw_KiB": raw}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
