@@ -35,8 +35,8 @@ int vllm_abi_version(void);
 const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
-/* Tuning / test knobs (process-wide).  "msda_tiled": 1 (default) lets the encoder-shaped MSDA forward use the
- * LDS-tiled kernel, 0 forces the plain gather kernel (same results to fp32 rounding).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
+/* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel: 0 plain gather kernel,
+ * 1 LDS-tiled kernel, 2 LDS-tiled + software-pipelined kernel (same results to fp32 rounding).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
  * kernel.  "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous
  * value or VLLM_EINVAL for an unknown name. */

@@ -229,10 +229,11 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
             }
 
             // ---- B: stage the window (LDS-DMA, 8 pixels of 128 B per wave instruction) ----
+            const unsigned ww_magic = (1u << 20) / (unsigned)ww + 1u;   // one scalar division per (block, level)
             for (int i0 = wave * 8; i0 < npix; i0 += 32) {
                 int pix = i0 + (lane >> 3);
                 pix = pix < npix ? pix : npix - 1;
-                const int wy = pix / ww, wx = pix - wy * ww;
+                const int wy = (int)(((unsigned)pix * ww_magic) >> 20), wx = pix - wy * ww;   // pix / ww, exact (pix*ww < 2^20)
                 const float *g = vl + ((long)(y0 + wy) * W + (x0w + wx)) * MD;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)(win + i0 * 32), 16, 0, 0);
@@ -298,9 +299,13 @@ bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const 
            (reinterpret_cast<uintptr_t>(loc) & 7u) == 0;
 }
 
+int msda_pipe_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                     const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_pipe.hip
+
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
+    if (msda_tiled_enabled() == 2) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     static int cus = 0;
     if (cus == 0) {
         hipDeviceProp_t prop;

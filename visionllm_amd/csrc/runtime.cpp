@@ -35,7 +35,8 @@ int msda_tiled_enabled()
 {
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
-        g_msda_tiled = e ? (atoi(e) != 0) : 1;
+        g_msda_tiled = e ? atoi(e) : 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 2) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -44,7 +45,12 @@ int msda_tiled_enabled()
 extern "C" int vllm_set_option(const char *name, int value)
 {
     if (!name) return VLLM_EINVAL;
-    if (!strcmp(name, "msda_tiled")) { const int old = vllm::msda_tiled_enabled(); vllm::g_msda_tiled = value != 0; return old; }
+    if (!strcmp(name, "msda_tiled")) {
+        const int old = vllm::msda_tiled_enabled();
+        if (value < 0 || value > 2) { vllm::set_error("msda_tiled must be 0..2"); return VLLM_EINVAL; }
+        vllm::g_msda_tiled = value;
+        return old;
+    }
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 7; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
