@@ -142,6 +142,11 @@ int vllm_im2col_patches(const void *pixels, int pixel_is_f32, uint16_t *A, int N
 int vllm_pixel_shuffle_bf16(const uint16_t *hidden, long tile_stride, int ld, int tok0, uint16_t *out,
                             int N, int hw, int C, vllm_stream_t stream);
 
+/* Visual-token splice (modeling_visionllmv2.py:582-605): dst[idx[i], :] = src[i, :] for i < n.  `idx` (device int64)
+ * holds the flattened [B*L_txt] positions of the <im_patch> slots; rows with idx outside [0, dst_rows) are skipped. */
+int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, uint16_t *dst, long n, int C, long dst_rows,
+                           vllm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * B1. Vision encoder (the `vis_encoder` slot): one call runs patch-embed + all layers.
  *

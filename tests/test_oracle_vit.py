@@ -53,3 +53,13 @@ def test_tile_grid():
     for w, h, isz, mx, n in rows.tolist():
         assert V.tile_grid(w, h, 1, mx, isz, True)[2] == n
     assert V.tile_grid(1336, 1336, 1, 4, 336)[2] == 5 and V.tile_grid(1336, 1336, 1, 6, 448)[2] == 5
+
+
+def test_product_tiling_matches_reference_fixture():
+    from visionllm_amd.tiling import dynamic_tile_grid, tile_boxes
+    rows = load_golden("tiling.npz")["rows"]
+    for w, h, isz, mx, n in rows.tolist():
+        c, r, nn = dynamic_tile_grid(w, h, 1, mx, isz, True)
+        assert nn == n and (c, r, nn) == V.tile_grid(w, h, 1, mx, isz, True)
+        assert len(tile_boxes(c, r, isz)) == c * r
+    assert dynamic_tile_grid(1336, 1336, 1, 4, 336)[2] == 5

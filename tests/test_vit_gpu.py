@@ -326,3 +326,38 @@ def test_bridge_vs_oracle(kind, ps):
     close(out, ref, 1.5e-2, f"bridge {kind} fused")
     out2 = br(feats.to(torch.bfloat16).to(DEV))          # drop-in path: the tensor the reference passes at :579
     close(out2, ref, 1.5e-2, f"bridge {kind} drop-in")
+
+
+def test_flash_attention_hook_and_rmsnorm_hook():
+    from visionllm_amd.flash_attention import FlashAttention
+    from visionllm_amd.intern_vit import InternRMSNorm
+    torch.manual_seed(0)
+    qkv = bf(torch.randn(2, 70, 3, 2, 64, device=DEV))
+    out, _ = FlashAttention()(qkv, key_padding_mask=None, causal=False)
+    close(out, _attn_ref(qkv.cpu(), 2, 64, 64 ** -0.5), 1e-2, "FlashAttention hook")
+    with pytest.raises(NotImplementedError):
+        FlashAttention()(qkv, causal=True)
+    n = InternRMSNorm(128, eps=1e-6).to(DEV).to(torch.bfloat16)
+    x = bf(torch.randn(3, 5, 128, device=DEV))
+    close(n(x), V.rms_norm(x.cpu(), n.weight.detach().cpu(), 1e-6), 8e-3, "InternRMSNorm hook")
+
+
+def test_visual_token_splice_matches_reference_semantics():
+    from visionllm_amd.splice import splice_visual_tokens
+    torch.manual_seed(1)
+    B, L, C, T = 3, 40, 64, 6
+    IMP = 7
+    ids = torch.randint(10, 50, (B, L))
+    ids[0, 3:3 + 2 * T] = IMP          # sample 0: two tiles
+    ids[2, 10:10 + T] = IMP            # sample 2: one tile; sample 1 has no image (its tile is dropped)
+    split = [2, 1, 1]
+    emb = bf(torch.randn(B, L, C))
+    feats = bf(torch.randn(sum(split), T, C))
+    # reference semantics (modeling_visionllmv2.py:582-605) in plain torch on the CPU
+    ref = emb.clone().reshape(B * L, C)
+    sel = ids == IMP
+    has = sel.sum(-1) != 0
+    has_t = torch.cat([has[i][None].repeat(split[i]) for i in range(B)])
+    ref[sel.reshape(-1)] = ref[sel.reshape(-1)] * 0.0 + feats[has_t].reshape(-1, C)
+    out = splice_visual_tokens(emb.clone().to(DEV), ids.to(DEV), IMP, feats.to(DEV), split)
+    assert torch.equal(out.cpu().reshape(B * L, C), ref)

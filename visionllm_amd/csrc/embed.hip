@@ -91,6 +91,21 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const uint16_t *__restric
     }
 }
 
+// dst[idx[i], :] = src[i, :]   (16-byte chunks; idx int64 on the device)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint16_t *__restrict__ src, const int64_t *__restrict__ idx,
+                                                           uint16_t *__restrict__ dst, long n, int C, long dst_rows)
+{
+    const int cch = C / 8;
+    const long nchunks = n * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % cch);
+        const long r = i / cch;
+        const long d = idx[r];
+        if (d >= 0 && d < dst_rows)
+            *reinterpret_cast<uint4_t *>(dst + d * C + ck * 8) = *reinterpret_cast<const uint4_t *>(src + r * C + ck * 8);
+    }
+}
+
 static inline unsigned grid_for(long n)
 {
     long b = (n + 255) / 256;
@@ -149,6 +164,18 @@ int drop_cls_launch(const uint16_t *in, long in_tile_stride, int ldin, uint16_t 
 }  // namespace vllm
 
 using namespace vllm;
+
+extern "C" int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, uint16_t *dst, long n, int C, long dst_rows,
+                                      vllm_stream_t stream)
+{
+    VLLM_REQUIRE(n >= 0 && C > 0 && C % 8 == 0, "scatter_rows: C must be a positive multiple of 8");
+    if (n == 0) return VLLM_OK;
+    VLLM_REQUIRE(src && idx && dst && aligned16(src) && aligned16(dst), "scatter_rows: null or unaligned pointer");
+    VLLM_LAUNCH(scatter_rows_kernel, dim3(grid_for(n * (C / 8))), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, C,
+                dst_rows);
+    VLLM_CHECK_LAUNCH("scatter_rows_kernel");
+    return VLLM_OK;
+}
 
 extern "C" int vllm_im2col_patches(const void *pixels, int pixel_is_f32, uint16_t *A, int N, int img, int patch,
                                    int Kpad, vllm_stream_t stream)
