@@ -206,6 +206,31 @@ def test_backward_f32_and_autograd_function():
     np.testing.assert_allclose(w.grad.cpu().numpy(), rw, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("D,M,P", [(32, 8, 4), (64, 2, 8), (16, 4, 2), (4, 3, 1), (128, 1, 4)])
+def test_backward_f32_vectorised_vs_oracle(D, M, P):
+    """fp32 backward through the vectorised kernel (D/4 a power of two) incl. rejected / border points."""
+    shapes = [(13, 11), (7, 6), (4, 3)]
+    g = make_inputs(2, M, D, shapes, P, Lq=77, mode="stress", seed=D + P)
+    rng = np.random.default_rng(3)
+    go = rng.standard_normal((2, 77, M * D)).astype(np.float32)
+    gv, gl, gw = A.ms_deform_attn_backward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]), _t(g["attw"]),
+                                           _t(go), 64)
+    rv, rl, rw = O.backward(g["value"].astype(np.float64), g["shapes"], g["lsi"], g["loc"].astype(np.float64),
+                            g["attw"].astype(np.float64), go.astype(np.float64))
+    # d/dloc is discontinuous at exact pixel borders, which the stress fixture contains (0.0 / 0.5 / 1.0): the fp32 and
+    # fp64 evaluations may pick different sides there -> compare away from those points
+    sel = np.ones(g["loc"].shape[:-1], dtype=bool)
+    for l, (H, W) in enumerate(shapes):
+        fy = g["loc"][:, :, :, l, :, 1].astype(np.float64) * H - 0.5
+        fx = g["loc"][:, :, :, l, :, 0].astype(np.float64) * W - 0.5
+        sel[:, :, :, l] &= ~((np.abs(fy - np.round(fy)) < 1e-4) | (np.abs(fx - np.round(fx)) < 1e-4))
+    np.testing.assert_allclose(gw.cpu().numpy()[sel], rw[sel], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gl.cpu().numpy()[sel], rl[sel], rtol=2e-3, atol=2e-3)
+    # grad_value sums contributions of all points; exclude nothing but allow the few border flips
+    bad = np.abs(gv.cpu().numpy() - rv) > 1e-3 * (1 + np.abs(rv))
+    assert bad.mean() < 2e-3, bad.mean()
+
+
 def test_modules_match_oracle_composition():
     """MSDeformAttn / mmcv module / GDINO module == (torch Linear layers + oracle op) on the same weights."""
     torch.manual_seed(0)

@@ -62,6 +62,14 @@ def main():
                          frac_of_8TBs=ab / sec / 8e12, gathered_TBs=gathered / sec / 1e12)
                 res.append(r)
                 print(json.dumps(r))
+    # backward (training of the det heads): encoder shape, fp32
+    g1 = make_inputs(1, 8, 32, CFG4_SHAPES, 4, mode="encoder_like", seed=0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in g1.items()}
+    for k in ("value", "loc", "attw"):
+        t[k] = t[k].repeat(a.B, *([1] * (t[k].dim() - 1))).contiguous()
+    go = torch.randn(a.B, t["loc"].shape[1], 256, device=dev)
+    sec = timeit(lambda: A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64), 5)
+    print(json.dumps(dict(mode="encoder_like", dtype="f32_backward", B=a.B, Lq=int(t["loc"].shape[1]), us=sec * 1e6)))
     return res
 
 

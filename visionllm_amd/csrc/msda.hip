@@ -303,6 +303,91 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Backward, vectorised (fp32, D/4 a power of two <= 64): same lane mapping as the forward gather kernel -- an
+// LPG-lane group per (b,q,m) pair, 4 channels per lane.  grad_value: hardware fp32 atomic adds (global_atomic_add_f32)
+// of 4 channels per corner per lane -- the same scatter the reference does with atomicAdd, 16 bytes wide per lane;
+// grad_sampling_loc / grad_attn_weight: per-lane partial over its 4 channels, then a log2(LPG)-step shuffle reduction
+// inside the group; one lane stores (each point has exactly one owner group, the outputs are plain stores).
+// Follows ms_deform_im2col_cuda.cuh:87-161 (col2im bilinear) and :301-360.
+// ---------------------------------------------------------------------------------------------------------
+template <int LPG, int PT>
+__global__ __launch_bounds__(MSDA_BLOCK) void msda_bwd_vec_kernel(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out, int S, int M,
+    int L, long n_pairs, long pairs_per_batch, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attw)
+{
+    constexpr int D = 4 * LPG;
+    constexpr int G = 64 / LPG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPG, sub = lane % LPG;
+    const long MD = (long)M * D;
+    for (long base = ((long)blockIdx.x * MSDA_WAVES + wave) * G; base < n_pairs; base += (long)gridDim.x * MSDA_WAVES * G) {
+        long pair = base + grp;
+        const bool live = pair < n_pairs;
+        pair = live ? pair : n_pairs - 1;
+        const int m = (int)(pair % M);
+        const long b = pair / pairs_per_batch;
+        const float4_t go = *reinterpret_cast<const float4_t *>(grad_out + pair * D + sub * 4);
+        const long vb = (b * (long)S) * MD + (long)m * D + sub * 4;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const long vl = vb + (long)lsi[l] * MD;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const long pi = (pair * L + l) * PT + p;
+                const float2_t xy = *reinterpret_cast<const float2_t *>(loc + pi * 2);
+                const float aw = attw[pi];
+                const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
+                const bool pok = sp.ok && live;
+                const int hl = sp.h_low, wl = sp.w_low;
+                const float lh = sp.h_im - (float)hl, lw = sp.w_im - (float)wl;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                const bool k1 = pok && hl >= 0 && wl >= 0, k2 = pok && hl >= 0 && wl + 1 <= W - 1;
+                const bool k3 = pok && hl + 1 <= H - 1 && wl >= 0, k4 = pok && hl + 1 <= H - 1 && wl + 1 <= W - 1;
+                const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
+                const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);
+                const long o1 = vl + ((long)h0 * W + x0) * MD, o2 = vl + ((long)h0 * W + x1) * MD;
+                const long o3 = vl + ((long)h1 * W + x0) * MD, o4 = vl + ((long)h1 * W + x1) * MD;
+                const float4_t v1 = *reinterpret_cast<const float4_t *>(value + o1);
+                const float4_t v2 = *reinterpret_cast<const float4_t *>(value + o2);
+                const float4_t v3 = *reinterpret_cast<const float4_t *>(value + o3);
+                const float4_t v4 = *reinterpret_cast<const float4_t *>(value + o4);
+                float g_aw = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float top = go[c], tgv = top * aw;
+                    const float a1 = k1 ? v1[c] : 0.f, a2 = k2 ? v2[c] : 0.f, a3 = k3 ? v3[c] : 0.f, a4 = k4 ? v4[c] : 0.f;
+                    // grad_h_weight / grad_w_weight of the reference (corner terms vanish when the corner is outside)
+                    const float ghw = -hw * a1 - lw * a2 + hw * a3 + lw * a4;
+                    const float gww = -hh * a1 + hh * a2 - lh * a3 + lh * a4;
+                    if (k1) unsafeAtomicAdd(grad_value + o1 + c, w1 * tgv);
+                    if (k2) unsafeAtomicAdd(grad_value + o2 + c, w2 * tgv);
+                    if (k3) unsafeAtomicAdd(grad_value + o3 + c, w3 * tgv);
+                    if (k4) unsafeAtomicAdd(grad_value + o4 + c, w4 * tgv);
+                    const float val = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4;
+                    g_aw += top * val;
+                    g_x += (float)W * gww * tgv;
+                    g_y += (float)H * ghw * tgv;
+                }
+#pragma unroll
+                for (int o = LPG >> 1; o > 0; o >>= 1) {
+                    g_aw += __shfl_xor(g_aw, o);
+                    g_x += __shfl_xor(g_x, o);
+                    g_y += __shfl_xor(g_y, o);
+                }
+                if (sub == 0 && pok) {   // rejected points keep the caller's zero fill
+                    grad_attw[pi] = g_aw;
+                    grad_loc[2 * pi] = g_x;
+                    grad_loc[2 * pi + 1] = g_y;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------------------
 static int check_dims(int B, int S, int M, int D, int L, int Lq, int P)
@@ -465,6 +550,25 @@ extern "C" int vllm_msda_sample_index_f32(const int64_t *shapes, const float *lo
     return VLLM_OK;
 }
 
+template <int LPG>
+static int launch_bwd_vec(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                          const float *attw, const float *grad_out, int B, int S, int M, int L, int Lq, int P, float *gv,
+                          float *gl, float *gw, hipStream_t st)
+{
+    constexpr int G = 64 / LPG;
+    const long n_pairs = (long)B * Lq * M;
+    long blocks = (n_pairs + G * MSDA_WAVES - 1) / (G * MSDA_WAVES);
+    const long cap = (long)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks), block(MSDA_BLOCK);
+#define LB(PT) VLLM_LAUNCH((msda_bwd_vec_kernel<LPG, PT>), grid, block, 0, st, value, shapes, lsi, loc, attw, grad_out, S, \
+                           M, L, n_pairs, (long)Lq * M, gv, gl, gw)
+    if (P == 4) LB(4); else if (P == 8) LB(8); else if (P == 2) LB(2); else LB(1);
+#undef LB
+    VLLM_CHECK_LAUNCH("msda_bwd_vec_kernel");
+    return VLLM_OK;
+}
+
 extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                                       const float *loc, const float *attw, const float *grad_out, int B, int S,
                                       int M, int D, int L, int Lq, int P, float *gv, float *gl, float *gw,
@@ -473,6 +577,17 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
     VLLM_REQUIRE((long)B * Lq == 0 || (value && shapes && lsi && loc && attw && grad_out && gv && gl && gw),
                  "msda_backward_f32: null pointer");
+    if ((long)B * Lq != 0 && D % 4 == 0 && (P == 1 || P == 2 || P == 4 || P == 8) && aligned16(value) &&
+        aligned16(grad_out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0) {
+        const int lpg = D / 4;
+        hipStream_t st = (hipStream_t)stream;
+        switch (lpg) {
+#define C(N) case N: return launch_bwd_vec<N>(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, P, gv, gl, gw, st)
+            C(1); C(2); C(4); C(8); C(16); C(32); C(64);
+#undef C
+        default: break;
+        }
+    }
     return launch_generic_bwd<float>(value, shapes, lsi, loc, attw, grad_out, B, S, M, D, L, Lq, P, gv, gl, gw,
                                      (hipStream_t)stream);
 }
