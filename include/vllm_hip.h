@@ -108,7 +108,8 @@ int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int
 /* Kernel choice is automatic (256x256 8-phase schedule for M,N >= 1024, 128x128 otherwise); OR one of these into
  * `epilogue` to force a schedule (parity tests / tuning only). */
 #define VLLM_GEMM_FORCE_128 0x100
-#define VLLM_GEMM_FORCE_256 0x200
+#define VLLM_GEMM_FORCE_256 0x200   /* 8-phase schedule, 256-row block tile */
+#define VLLM_GEMM_FORCE_192 0x300   /* 8-phase schedule, 192-row block tile */
 
 /* Y[M,N] = epilogue(X[M,K] @ W[N,K]^T + bias).  Replaces F.linear / nn.Conv2d-as-GEMM on the path
  * (modeling_intern_vit.py:112,124,128,141,172-178; modeling_visionllmv2.py:162-182).

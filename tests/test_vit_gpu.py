@@ -48,7 +48,7 @@ def close(out, ref, tol=1e-2, what=""):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (577, 1024, 1024), (1000, 3200, 192), (77, 64, 640),
                                    (2 * 577, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("force", [0x100, 0x200])   # both schedules: 128x128 2-stage and 256x256 8-phase
+@pytest.mark.parametrize("force", [0x100, 0x200, 0x300])   # 128x128 2-stage, 8-phase 256-row, 8-phase 192-row
 def test_gemm_epilogues(M, N, K, epi, force):
     torch.manual_seed(M + N + K + epi)
     x = bf(torch.randn(M, K, device=DEV))
@@ -69,7 +69,7 @@ def test_gemm_epilogues(M, N, K, epi, force):
     close(y, z, 1e-2, f"gemm epi {epi}")
 
 
-@pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512)])
+@pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512), (0x300, 128), (0x300, 576)])
 def test_gemm_transpose_detecting(force, M):
     """A = I-like and asymmetric B (cdna guide G9): catches swapped operands / transposed stores."""
     N = K = M
@@ -92,13 +92,14 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
     b = bf(torch.randn(N, device=DEV))
     ys = []
-    for force in (0x200, 0x200, 0x200, 0x100):
+    for force in (0x200, 0x200, 0x300, 0x300, 0x100):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, force, None, None, 0, 0, stream()))
         ys.append(y)
     torch.cuda.synchronize()
-    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
-    close(ys[0], ys[3], 4e-3, "256 vs 128 kernel")
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[2], ys[3])
+    close(ys[0], ys[4], 4e-3, "256 vs 128 kernel")
+    close(ys[2], ys[4], 4e-3, "192 vs 128 kernel")
     ref = x[:257].float() @ w.float().t() + b.float()
     close(ys[0][:257], ref, 1e-2, "256 kernel vs fp32")
 
@@ -172,6 +173,27 @@ def test_attention_online_softmax_rescale_branch(D):
     ref = _attn_ref(qkv.cpu(), H, D, D ** -0.5)
     assert torch.isfinite(out.float()).all()
     close(out, ref, 1.5e-2, "attention with spiked keys")
+
+
+@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3])
+@pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
+def test_attention_schedule_variants(variant, D, S):
+    """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""
+    torch.manual_seed(variant + S)
+    B, H = 2, 2
+    qkv = torch.randn(B, S, 3, H, D, device=DEV) * 0.7
+    qkv[0, S // 2, 1, 0] = qkv[0, 7, 0, 0] * 6.0     # a spiked key in a middle tile (rescale path)
+    qkv = bf(qkv)
+    old = _lib.set_option("attn_variant", variant)
+    try:
+        out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
+        _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))
+        out2 = torch.empty_like(out)
+        _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out2), B, S, H, D, D ** -0.5, stream()))
+    finally:
+        _lib.set_option("attn_variant", old)
+    assert torch.equal(out, out2)
+    close(out, _attn_ref(qkv.cpu(), H, D, D ** -0.5), 1.5e-2, f"attention variant {variant}")
 
 
 def test_attention_rejects_head_dim():

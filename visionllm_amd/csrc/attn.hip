@@ -55,11 +55,13 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
 }
 
 // VAR bit0: software-pipelined K (scores of tile t+1 next to the softmax of tile t); bit1: deferred rescale;
-// bit2: s_setprio(1) around the MFMA clusters.
+// bit2: s_setprio(1) around the MFMA clusters; bit3: V transpose-reads issued as inline asm BEFORE the softmax (the
+// compiler treats the tr-read builtin as 'may alias the LDS-DMA in flight' and puts s_waitcnt vmcnt(0) in front of it,
+// which drains the next tile's prefetch in the middle of every iteration).
 template <int D, int VAR>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs a)
 {
-    constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0;
+    constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0, ASMTR = (VAR & 8) != 0;
     constexpr int KS = D / 16;            // k-steps of the QK^T product
     constexpr int DB = D / 32;            // 32-wide output blocks
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
@@ -120,6 +122,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
     // max grows by less than THR (exp2 domain): P is then bounded by 2^THR instead of 1 (fp32 accumulation).
     auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0) {
         constexpr float THR = DEFER ? 6.0f : 0.0f;
+        constexpr int NHOIST = ASMTR ? 16 : 1;          // tr-reads hoisted above the softmax: steps (kb,u) x d blocks
+        s16x4_t hv[NHOIST];                              // D=64: all 16 reads of the tile; D=128: the kb=0 half
+        if constexpr (ASMTR) {
+            const uint32_t vbase = (uint32_t)(uintptr_t)vs_;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // i -> (step, d, lo/hi) in the order the PV loop consumes them
+                const int per_step = 2 * DB;
+                const int step = i / per_step, rem = i % per_step, d = rem >> 1, hi_ = rem & 1;
+                const int kb = step >> 1, u = step & 1;
+                const int key = kb * 32 + 16 * u + 4 * hh + (i16 >> 2) + 8 * hi_;
+                const int c = d * 4 + 2 * g1 + ((i16 & 3) >> 1);
+                const uint32_t addr = vbase + key * (D * 2) + ((c ^ swz_v<D>(key)) << 4) + ((i16 & 1) << 3);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hv[i]) : "v"(addr));
+            }
+        }
         float mx = -1.0e30f;
         if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
 #pragma unroll
@@ -158,6 +176,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
             }
         l_run += psum;
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
+        if constexpr (ASMTR) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the hoisted reads have landed (cdna guide 5.7, form iii)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -172,10 +194,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 for (int d = 0; d < DB; ++d) {
                     const int c = d * 4 + 2 * g1 + ((i16 & 3) >> 1);
                     const int sub = (i16 & 1) << 3;
-                    const s16x4_t v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t *)(vs_ + key1 * (D * 2) + ((c ^ swz_v<D>(key1)) << 4) + sub));
-                    const s16x4_t v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t *)(vs_ + key2 * (D * 2) + ((c ^ swz_v<D>(key2)) << 4) + sub));
+                    const int hidx = ((kb * 2 + u) * DB + d) * 2;   // position in the hoisted set (if it is in it)
+                    s16x4_t v_lo, v_hi;
+                    if (ASMTR && hidx + 1 < NHOIST) {
+                        v_lo = hv[hidx < NHOIST ? hidx : 0];
+                        v_hi = hv[hidx + 1 < NHOIST ? hidx + 1 : 0];
+                    } else {
+                        v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + key1 * (D * 2) + ((c ^ swz_v<D>(key1)) << 4) + sub));
+                        v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + key2 * (D * 2) + ((c ^ swz_v<D>(key2)) << 4) + sub));
+                    }
                     const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                 }
@@ -260,10 +289,11 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    const int var = attn_variant() & 7;
+    const int var = attn_variant() & 15;
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
-#define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 1: LA(DD, 1); break; case 2: LA(DD, 2); break; \
-    case 3: LA(DD, 3); break; case 4: LA(DD, 4); break; case 5: LA(DD, 5); break; case 6: LA(DD, 6); break; default: LA(DD, 7); } } while (0)
+#define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 2: LA(DD, 2); break; case 6: LA(DD, 6); break; \
+    case 8: LA(DD, 8); break; case 10: LA(DD, 10); break; case 14: LA(DD, 14); break; case 3: LA(DD, 3); break; \
+    default: LA(DD, 2); } } while (0)
     if (D == 64) LV(64); else LV(128);
 #undef LV
 #undef LA

@@ -175,7 +175,9 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     VLLM_REQUIRE(X && W && Y, "vllm_gemm_bf16: null pointer");
     GemmArgs a;
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
-    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override();
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0;
     if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;   // VLLM_GEMM_FORCE_* (tests / tuning)
+    if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }   // VLLM_GEMM_FORCE_192
+    else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
 }

@@ -23,20 +23,24 @@ namespace vllm {
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
+constexpr int G2_BN = 256, G2_BK = 64;   // block rows are 64 * MT (template parameter)
 constexpr int G2_THREADS = 512;
 constexpr int G2_HALF = 128 * G2_BK * 2;          // 16 KiB half-tile
 constexpr int G2_STAGE = 4 * G2_HALF;             // A0 A1 B0 B1
 constexpr int OFF_A0 = 0, OFF_A1 = G2_HALF, OFF_B0 = 2 * G2_HALF, OFF_B1 = 3 * G2_HALF;
 
-// Refill one 128-row half-tile: 16 LDS-DMA instructions of 8 rows, 2 per wave.
+// Refill one half-tile of NSEG x 8 rows (NSEG <= 16): one LDS-DMA instruction per 8 rows, EXACTLY 2 per wave (the counted
+// vmcnt waits assume that): waves whose segments do not exist (NSEG < 16) reload the last real segment into the unused
+// tail of the 16 KiB slot.
+template <int NSEG>
 __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int ld, int row0, int nrows, int k0,
                                            char *lds_half, int wave, int lane, int skipP)
 {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int seg = wave * 2 + s;
-        const int r = seg * 8 + (lane >> 3);
+        const int sseg = seg < NSEG ? seg : NSEG - 1;      // source segment (dummy reload for idle slots)
+        const int r = sseg * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);
         int grow = row0 + r;
         grow = grow < nrows ? grow : nrows - 1;
@@ -54,7 +58,9 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
         __builtin_amdgcn_sched_barrier(0);\
     } while (0)
 
-template <int EPI>
+// MT = 16-row m tiles per wave per A half: 4 -> 256-row block tile, 3 -> 192 rows (better tile-count quantisation on
+// 256 CUs for some shapes: 23080 x 1024 is 364 tiles = 1.42 rounds at 256 rows but 484 = 1.89 rounds at 192).
+template <int EPI, int MT>
 __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
@@ -76,22 +82,23 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         }
         if (tm_idx >= a.mt || tn_idx >= a.nt) return;
     }
-    const int m0 = tm_idx * G2_BM, n0 = tn_idx * G2_BN;
+    constexpr int BM_ = 64 * MT;                  // block rows: 2 halves x 2 wave rows x MT x 16
+    const int m0 = tm_idx * BM_, n0 = tn_idx * G2_BN;
     const int nk = a.K / G2_BK;
 
-    f32x4_t acc[4][2][4];   // [quadrant q = 2*i + j][n tile][m tile]
+    f32x4_t acc[4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MT; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS byte offsets inside a half-tile for the two fragment kinds (ks = 0 / 1 differ by XOR 4 chunks)
-    int xoff[4], woff[2];
+    int xoff[MT], woff[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int r = wr * 64 + t * 16 + fr;
+    for (int t = 0; t < MT; ++t) {
+        const int r = wr * (16 * MT) + t * 16 + fr;
         xoff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
     }
 #pragma unroll
@@ -99,20 +106,20 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         const int r = wc * 32 + t * 16 + fr;
         woff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
     }
-    bf16x8_t xf[4][2], wf[2][2];
+    bf16x8_t xf[MT][2], wf[2][2];
 
     auto k_of = [&](int t) { return (t < nk ? t : nk - 1) * G2_BK; };   // clamped: tail refills are harmless
     auto issue_A = [&](int half, int stage, int t) {
-        issue_half(a.X, a.ldx, m0 + half * 128, a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0), wave,
-                   lane, a.xP);
+        issue_half<4 * MT>(a.X, a.ldx, m0 + half * (32 * MT), a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0),
+                           wave, lane, a.xP);
     };
     auto issue_B = [&](int half, int stage, int t) {
-        issue_half(a.W, a.ldw, n0 + half * 128, a.N, k_of(t), smem + stage * G2_STAGE + (half ? OFF_B1 : OFF_B0), wave,
-                   lane, 0);
+        issue_half<16>(a.W, a.ldw, n0 + half * 128, a.N, k_of(t), smem + stage * G2_STAGE + (half ? OFF_B1 : OFF_B0), wave,
+                       lane, 0);
     };
     auto read_x = [&](const char *half) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < MT; ++t) {
             xf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + xoff[t]);
             xf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[t] ^ 64));   // chunk index + 4  (ks = 1)
         }
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         __builtin_amdgcn_s_setprio(1);                                                                          \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+                _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                  \
                     acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], xf[j][ks], acc[Q][i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -184,8 +191,8 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             if (n >= a.N) continue;
             const EpiCols cols = epi_cols<EPI>(a, n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + qi * 128 + wr * 64 + j * 16 + fr;
+            for (int j = 0; j < MT; ++j) {
+                const int m = m0 + qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr;
                 if (m >= a.M) continue;
                 epi_store<EPI>(a, m, n, acc[q][i][j], cols);
             }
@@ -195,8 +202,23 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
 
 int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 {
-    a.mt = ceil_div(a.M, G2_BM);
+    static int cus = 0;
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
     a.nt = ceil_div(a.N, G2_BN);
+    // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
+    auto cost = [&](int mt_rows) {
+        const long tiles = (long)ceil_div(a.M, 64 * mt_rows) * a.nt;
+        // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
+        return ((tiles + cus - 1) / cus) * (long)(mt_rows == 4 ? 100 : 87);
+    };
+    int MT = cost(3) < cost(4) ? 3 : 4;
+    if (a.variant256 == 3 || a.variant256 == 4) MT = a.variant256;
+    a.mt = ceil_div(a.M, 64 * MT);
     long tiles;
     if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
     else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;
@@ -204,12 +226,14 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     const size_t lds = 2 * G2_STAGE;   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-#define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SETATTR(EPI_BIAS); SETATTR(EPI_GELU); SETATTR(EPI_QUICK_GELU); SETATTR(EPI_RESIDUAL); SETATTR(EPI_EMBED);
 #undef SETATTR
         attr_set = true;
     }
-#define L(E) VLLM_LAUNCH((gemm256_bf16_kernel<E>), grid, block, lds, st, a)
+#define L(E) do { if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4>), grid, block, lds, st, a); \
+                  else VLLM_LAUNCH((gemm256_bf16_kernel<E, 3>), grid, block, lds, st, a); } while (0)
     switch (epi) {
     case EPI_BIAS: L(EPI_BIAS); break;
     case EPI_GELU: L(EPI_GELU); break;

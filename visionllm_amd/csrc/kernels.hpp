@@ -25,6 +25,7 @@ struct GemmArgs {
     int mt, nt;             // tile counts (filled by the launcher)
     int xP;                 // >0: X is [n, 1+xP, K] and row m reads X row m + m/xP + 1 (CLS rows skipped)
     int variant;            // 0 auto, 1 force 128x128 kernel, 2 force 256x256 8-phase kernel (tuning / tests)
+    int variant256;         // 8-phase kernel block rows: 0 auto, 3 -> 192, 4 -> 256
 };
 
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
@@ -39,7 +40,7 @@ inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint1
 {
     GemmArgs a;
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
-    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP; a.variant = gemm_variant_override();
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP; a.variant = gemm_variant_override(); a.variant256 = 0;
     return gemm_bf16_launch(epi, a, st);
 }
 

@@ -18,7 +18,7 @@ int attn_variant()
 {
     if (g_attn_variant < 0) {
         const char *e = getenv("VLLM_ATTN_VARIANT");
-        g_attn_variant = e ? (atoi(e) & 7) : 2;
+        g_attn_variant = e ? (atoi(e) & 15) : 2;
     }
     return g_attn_variant;
 }
@@ -51,7 +51,7 @@ extern "C" int vllm_set_option(const char *name, int value)
         vllm::g_msda_tiled = value;
         return old;
     }
-    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 7; return old; }
+    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 15; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
         if (value < 0 || value > 2) { vllm::set_error("gemm_variant must be 0..2"); return VLLM_EINVAL; }
