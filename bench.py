@@ -262,12 +262,15 @@ def main():
     def step():
         out = enc(pixels, output_hidden_states=True)
         tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
-        gathered, _ = all_gather_visual_tokens(tokens)
-        res = [gathered]
+        # the token all-gather (RCCL over xGMI, its own stream) overlaps the det-head MSDA kernels of this step
+        handle = all_gather_visual_tokens(tokens, counts=[tokens.shape[0]] * world, async_op=True)
+        res = []
         for tag, n in (("enc", MSDA["enc_layers"]), ("dec", MSDA["dec_layers"])):
             t = msda_in[tag]
             for _ in range(n):
                 res.append(A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64))
+        gathered, _ = handle.wait()
+        res.append(gathered)
         return res
 
     for _ in range(args.warmup):

@@ -59,3 +59,16 @@ def test_module_constructor_errors_mirror_reference():
         MultiScaleDeformableAttention(embed_dims=256, num_heads=7)
     with pytest.raises(ValueError):
         MSDeformAttn(d_model=256, n_heads=7)
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without the built .so every op raises (the product never routes through the oracle)."""
+    import torch
+    from visionllm_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "lib_path", lambda: str(tmp_path / "libvllm_hip.so"))
+    with pytest.raises(RuntimeError, match="has not been built"):
+        L.lib()
+    from visionllm_amd.bridge import pixel_shuffle
+    with pytest.raises(RuntimeError):
+        pixel_shuffle(torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16))

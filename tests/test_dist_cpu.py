@@ -34,6 +34,10 @@ def _worker(rank, world, port, ragged, q):
     torch.manual_seed(rank)
     tok = (torch.arange(n * 4 * 8, dtype=torch.float32).reshape(n, 4, 8) + 1000 * rank).to(torch.bfloat16)
     out, counts = all_gather_visual_tokens(tok)
+    # the asynchronous form with caller-provided counts (no count exchange, no host sync) must give the same result
+    h = all_gather_visual_tokens(tok, counts=counts, async_op=True)
+    out2, counts2 = h.wait()
+    assert counts2 == counts and torch.equal(out2, out)
     q.put((rank, out.float(), counts))
     dist.destroy_process_group()
 

@@ -383,3 +383,47 @@ def test_visual_token_splice_matches_reference_semantics():
     ref[sel.reshape(-1)] = ref[sel.reshape(-1)] * 0.0 + feats[has_t].reshape(-1, C)
     out = splice_visual_tokens(emb.clone().to(DEV), ids.to(DEV), IMP, feats.to(DEV), split)
     assert torch.equal(out.cpu().reshape(B * L, C), ref)
+
+
+def test_cfg1_vitl14_336_full_depth_plus_bridge_vs_oracle():
+    """BASELINE configs[0]: ViT-L/14 encoder + projector on one 336x336 random image (full 24 layers), HIP (bf16) vs
+    the fp32 oracle and vs the oracle run in bf16 (the reference's own precision).  Prints the measured errors."""
+    from transformers import CLIPVisionConfig
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=24, image_size=336,
+                patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    model = CLIPVisionModel(CLIPVisionConfig(**cfgd))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0, 0.02)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if "position_ids" not in k}
+    torch.manual_seed(1)
+    br = build_vl_bridge("mlp2x_gelu", 1024, 4096, use_pixelshuffle=False)
+    bsd = {k: bf(v.detach()).float() for k, v in br.state_dict().items()}
+    x = torch.randn(1, 3, 336, 336)
+    model = model.to(DEV).to(torch.bfloat16)
+    br = br.to(DEV).to(torch.bfloat16)
+    out = model(bf(x).to(DEV), output_hidden_states=True)
+    tok = br.project_hidden_state(out.hidden_states[-2], False)
+    fwd = lambda s, c, xx: V.clip_vit_forward(s, c, xx, prefix="vision_model.")  # noqa: E731
+    ref, lo = _oracle_errors(fwd, sd, cfgd, x)
+    assert len(out.hidden_states) == 25 and tok.shape == (1, 576, 4096)
+    rtok = V.bridge_forward(bsd, "mlp2x_gelu", V.select_features(ref, -2, False))
+    ltok = V.bridge_forward({k: bf(v) for k, v in bsd.items()}, "mlp2x_gelu", V.select_features(lo, -2, False))
+    h_ours, h_lo, h_ref = out.hidden_states[-2].float().cpu(), lo[-2].float(), ref[-2]
+    e_h = (h_ours - h_ref).abs().max().item(); e_hlo = (h_lo - h_ref).abs().max().item()
+    e_t = (tok.float().cpu() - rtok).abs().max().item(); e_tlo = (ltok.float() - rtok).abs().max().item()
+    rms_t = ((tok.float().cpu() - rtok).pow(2).mean().sqrt() / rtok.pow(2).mean().sqrt()).item()
+    rms_tlo = ((ltok.float() - rtok).pow(2).mean().sqrt() / rtok.pow(2).mean().sqrt()).item()
+    msg = (f"cfg1: hs[-2] max|err| ours {e_h:.4g} (oracle-in-bf16 {e_hlo:.4g}, scale {h_ref.abs().max():.3g}); "
+           f"tokens max|err| ours {e_t:.4g} (oracle-in-bf16 {e_tlo:.4g}, scale {rtok.abs().max():.3g}), "
+           f"rel rms ours {rms_t:.3g} (oracle-in-bf16 {rms_tlo:.3g})")
+    print(msg)
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/cfg1_parity.txt", "w").write(msg + "\n")
+    # after 24 bf16 layers the yardstick is the error the reference's own bf16 path makes against fp32
+    assert e_h <= max(2.0 * e_hlo, 1e-2 * h_ref.abs().max().item())
+    assert e_t <= max(2.0 * e_tlo, 1e-2 * rtok.abs().max().item())
+    assert rms_t <= max(1.5 * rms_tlo, 1e-2)

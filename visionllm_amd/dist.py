@@ -27,17 +27,42 @@ def shard_images(tiles_per_image: Sequence[int], world_size: int) -> List[List[i
     return [sorted(x) for x in out]
 
 
-def all_gather_visual_tokens(tokens: torch.Tensor, group=None) -> Tuple[torch.Tensor, List[int]]:
+class GatherHandle:
+    """Result of an asynchronous ``all_gather_visual_tokens``: call ``wait()`` to get (tokens, tiles per rank)."""
+
+    def __init__(self, work, out, counts, mx):
+        self._work, self._out, self._counts, self._mx = work, out, counts, mx
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()   # makes the current stream wait for the collective (no host sync with NCCL/RCCL)
+            self._work = None
+        out, counts, mx = self._out, self._counts, self._mx
+        if len(counts) == 1 or all(c == mx for c in counts):
+            return out, counts
+        return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(len(counts))], 0), counts
+
+
+def all_gather_visual_tokens(tokens: torch.Tensor, group=None, counts: Sequence[int] = None, async_op: bool = False):
     """tokens [n_tiles_r, T, C] -> ([sum_r n_tiles_r, T, C] in rank order, tiles per rank).
 
-    One small all-gather of the counts, one large all-gather of the (padded) payload."""
+    One small all-gather of the counts (skipped when the caller passes ``counts`` -- e.g. it sharded the images itself
+    with ``shard_images`` -- which also avoids the host sync of reading them back), one large all-gather of the
+    (padded) payload.  ``async_op=True`` returns a ``GatherHandle`` immediately: the collective runs on RCCL's stream
+    over xGMI while the caller keeps enqueuing independent work (the det-head kernels) on the compute stream."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return tokens, [tokens.shape[0]]
+        res = (tokens, [tokens.shape[0]])
+        return GatherHandle(None, res[0], res[1], tokens.shape[0]) if async_op else res
     ws = dist.get_world_size(group)
-    n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=tokens.device)
-    counts = torch.empty(ws, dtype=torch.int64, device=tokens.device)
-    dist.all_gather_into_tensor(counts, n, group=group)
-    counts_l = [int(c) for c in counts.tolist()]
+    if counts is None:
+        n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=tokens.device)
+        cnt = torch.empty(ws, dtype=torch.int64, device=tokens.device)
+        dist.all_gather_into_tensor(cnt, n, group=group)
+        counts_l = [int(c) for c in cnt.tolist()]
+    else:
+        counts_l = [int(c) for c in counts]
+        if len(counts_l) != ws or counts_l[dist.get_rank(group)] != tokens.shape[0]:
+            raise ValueError("all_gather_visual_tokens: `counts` must list the tile count of every rank")
     mx = max(counts_l)
     T, C = tokens.shape[1], tokens.shape[2]
     if tokens.shape[0] != mx:
@@ -45,7 +70,6 @@ def all_gather_visual_tokens(tokens: torch.Tensor, group=None) -> Tuple[torch.Te
         pad[: tokens.shape[0]] = tokens
         tokens = pad
     out = torch.empty((ws * mx, T, C), dtype=tokens.dtype, device=tokens.device)
-    dist.all_gather_into_tensor(out, tokens.contiguous(), group=group)
-    if all(c == mx for c in counts_l):
-        return out, counts_l
-    return torch.cat([out[r * mx: r * mx + counts_l[r]] for r in range(ws)], 0), counts_l
+    work = dist.all_gather_into_tensor(out, tokens.contiguous(), group=group, async_op=async_op)
+    h = GatherHandle(work if async_op else None, out, counts_l, mx)
+    return h if async_op else h.wait()
