@@ -41,6 +41,9 @@ int vllm_device_info(char *name, int cap);
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous
  * value or VLLM_EINVAL for an unknown name. */
 int vllm_set_option(const char *name, int value);
+/* Diagnostics: with "msda_tiled" = 6 the LDS-tiled MSDA kernel adds per-phase shader-clock ticks (wave 0 of every block) to
+ * 16 device counters; this reads them into out[0..n) and clears them.  Returns the number of counters written. */
+int vllm_debug_counters(long *out, int n);
 
 /* ------------------------------------------------------------------------------------------------
  * B3. Multi-scale deformable attention (MSDA) operator.

@@ -20,17 +20,19 @@
 
 namespace vllm {
 
-constexpr int MT_TH = 8, MT_TW = 16;             // query tile (rows x cols of one level)
 constexpr int MT_THREADS = 256;
-constexpr int MT_NQ = MT_TH * MT_TW;             // 128 queries per block
 constexpr int MT_QPP = MT_THREADS / 8;           // 32 queries per pass (8 lanes x 16 B = D 32 fp32)
-constexpr int MT_NPASS = MT_NQ / MT_QPP;         // 4
-constexpr int MT_WIN_MAX = 560;                  // window budget in pixels (x 128 B); 2 blocks per CU
-constexpr int MT_ZP = MT_WIN_MAX + 8;            // index of the all-zero pixel (behind the LDS-DMA slack)
 constexpr int MT_MAXL = 8;
-constexpr size_t MT_LDS_WIN = (size_t)(MT_ZP + 1) * 128;
-constexpr size_t MT_LDS_LOC = MT_NQ * 4 * 8, MT_LDS_AW = MT_NQ * 4 * 4;   // per-level loc (float2) / weights
-constexpr size_t MT_LDS = MT_LDS_WIN + MT_LDS_LOC + MT_LDS_AW;
+
+// Tile configuration: TH x TW queries of one level per block, window budget WIN pixels (x 128 B), BPC blocks per CU.
+//   <8,16,560,2>: big tiles, fewer halo re-reads, 2 blocks (8 waves) per CU
+//   <8, 8,288,4>: small tiles -> small windows and half the per-lane state -> 4 blocks (16 waves) per CU
+template <int TH_, int TW_, int WIN_, int BPC_>
+struct MTCfg {
+    static constexpr int TH = TH_, TW = TW_, NQ = TH_ * TW_, NPASS = NQ / MT_QPP, WIN_MAX = WIN_, ZP = WIN_ + 8, BPC = BPC_;
+    static constexpr size_t LDS_WIN = (size_t)(ZP + 1) * 128, LDS_LOC = (size_t)NQ * 4 * 8, LDS_AW = (size_t)NQ * 4 * 4;
+    static constexpr size_t LDS = LDS_WIN + LDS_LOC + LDS_AW;
+};
 
 template <int K>
 __device__ __forceinline__ float quad_bcast(float x)   // value of lane K of this lane's quad
@@ -45,13 +47,13 @@ __device__ __forceinline__ int quad_bcast(int x)
 
 // Global-memory fallback for one (block, level) whose window exceeds the LDS budget: the gather kernel's code,
 // with loc / weights read from the LDS copy.
-template <int PT>
-__device__ __forceinline__ void gather_level_global(float (&acc)[MT_NPASS][4], const bool (&qok)[MT_NPASS],
+template <int PT, typename Cfg>
+__device__ __forceinline__ void gather_level_global(float (&acc)[Cfg::NPASS][4], const bool (&qok)[Cfg::NPASS],
                                                     const float2_t *s_loc, const float *s_aw, int slot0, int H, int W,
                                                     const float *__restrict__ vl, long MD)
 {
 #pragma unroll
-    for (int p = 0; p < MT_NPASS; ++p) {
+    for (int p = 0; p < Cfg::NPASS; ++p) {
         const int slot = p * MT_QPP + slot0;
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
@@ -85,8 +87,8 @@ __device__ __forceinline__ void gather_level_global(float (&acc)[MT_NPASS][4], c
     }
 }
 
-template <int PT>
-__global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
+template <int PT, typename Cfg>
+__global__ __launch_bounds__(MT_THREADS, Cfg::BPC) void msda_fwd_tiled_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
     float *__restrict__ out)
@@ -94,9 +96,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
     static_assert(PT == 4, "one sampling point per lane of a quad");
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *win = reinterpret_cast<float *>(smem);                               // [(MT_ZP + 1) pixels][32]
-    float2_t *s_loc = reinterpret_cast<float2_t *>(smem + MT_LDS_WIN);            // [128 queries][4 points]
-    float *s_aw = reinterpret_cast<float *>(smem + MT_LDS_WIN + MT_LDS_LOC);      // [128 queries][4 points]
+    float *win = reinterpret_cast<float *>(smem);                               // [(Cfg::ZP + 1) pixels][32]
+    float2_t *s_loc = reinterpret_cast<float2_t *>(smem + Cfg::LDS_WIN);            // [128 queries][4 points]
+    float *s_aw = reinterpret_cast<float *>(smem + Cfg::LDS_WIN + Cfg::LDS_LOC);      // [128 queries][4 points]
     __shared__ int s_H[MT_MAXL], s_W[MT_MAXL], s_q0[MT_MAXL], s_tc[MT_MAXL + 1];
     __shared__ long s_v0[MT_MAXL];
     __shared__ int s_red[4][4];
@@ -115,16 +117,16 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
             s_H[l] = H; s_W[l] = W; s_q0[l] = (int)cum; s_v0[l] = (long)lsi[l]; s_tc[l] = tc;
-            tc += ((H + MT_TH - 1) / MT_TH) * ((W + MT_TW - 1) / MT_TW);
+            tc += ((H + Cfg::TH - 1) / Cfg::TH) * ((W + Cfg::TW - 1) / Cfg::TW);
             cum += (long)H * W;
         }
         s_tc[L] = tc;
         s_geo_ok = (cum == (long)Lq);
     }
-    if (tid < 32) win[MT_ZP * 32 + tid] = 0.f;
+    if (tid < 32) win[Cfg::ZP * 32 + tid] = 0.f;
     __syncthreads();
     const bool geo = s_geo_ok != 0;
-    const int n_tiles = geo ? s_tc[L] : (Lq + MT_TW - 1) / MT_TW;
+    const int n_tiles = geo ? s_tc[L] : (Lq + Cfg::TW - 1) / Cfg::TW;
     const long n_items = (long)B * M * n_tiles;
 
     const int xcd = blockIdx.x & 7;
@@ -143,24 +145,24 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
             int lq = 0;
             while (lq + 1 < L && s_tc[lq + 1] <= t) ++lq;
             qH = s_H[lq]; qW = s_W[lq]; q0 = s_q0[lq];
-            const int txn = (qW + MT_TW - 1) / MT_TW, tl = t - s_tc[lq];
+            const int txn = (qW + Cfg::TW - 1) / Cfg::TW, tl = t - s_tc[lq];
             ty = tl / txn; tx = tl - ty * txn;
         } else {
             qH = 1; qW = Lq; q0 = 0; ty = 0; tx = t;
         }
         // (b, q, m) pair index of tile slot s (clamped to a live query) and whether the slot is live
         auto pair_of = [&](int slot, bool &ok) -> long {
-            const int y = ty * MT_TH + slot / MT_TW, x = tx * MT_TW + slot % MT_TW;
+            const int y = ty * Cfg::TH + slot / Cfg::TW, x = tx * Cfg::TW + slot % Cfg::TW;
             ok = y < qH && x < qW;
             const long q = q0 + (long)(ok ? y : 0) * qW + (ok ? x : 0);
             return (b * Lq + q) * M + m;
         };
 
-        long qidx[MT_NPASS];
-        bool qok[MT_NPASS];
-        float acc[MT_NPASS][4];
+        long qidx[Cfg::NPASS];
+        bool qok[Cfg::NPASS];
+        float acc[Cfg::NPASS][4];
 #pragma unroll
-        for (int p = 0; p < MT_NPASS; ++p) {
+        for (int p = 0; p < Cfg::NPASS; ++p) {
             qidx[p] = pair_of(p * MT_QPP + slot0, qok[p]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
@@ -168,34 +170,36 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
         // cooperative loc / weight loads: thread i -> query slot i>>1, points 2*(i&1).. ; weights: threads < 128
         bool lq_ok, aq_ok;
         const long lq_pair = pair_of(tid >> 1, lq_ok);
-        const long aq_pair = pair_of(tid & (MT_NQ - 1), aq_ok);
+        const long aq_pair = pair_of(tid & (Cfg::NQ - 1), aq_ok);
 
         // loc / weights of level l+1 are fetched into registers while level l is processed (the global latency would
         // otherwise be exposed twice per level: once here, once for the window)
-        float4_t nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + 0) * (PT * 2) + (tid & 1) * 4);
+        const bool lthr = tid < Cfg::NQ * 2;
+        float4_t nloc = {0.f, 0.f, 0.f, 0.f};
+        if (lthr) nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + 0) * (PT * 2) + (tid & 1) * 4);
         float4_t naw = {0.f, 0.f, 0.f, 0.f};
-        if (tid < MT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + 0) * PT);
+        if (tid < Cfg::NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + 0) * PT);
 
         for (int l = 0; l < L; ++l) {
             const int H = s_H[l], W = s_W[l];
             const float *vl = value + (b * (long)S + s_v0[l]) * MD + (long)m * D + sub * 4;
 
             __syncthreads();   // previous level / item: every read of s_loc, s_aw, win, s_red is finished
-            reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
-            if (tid < MT_NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
+            if (lthr) reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
+            if (tid < Cfg::NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
             if (l + 1 < L) {
-                nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l + 1) * (PT * 2) + (tid & 1) * 4);
-                if (tid < MT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l + 1) * PT);
+                if (lthr) nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l + 1) * (PT * 2) + (tid & 1) * 4);
+                if (tid < Cfg::NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l + 1) * PT);
             }
             __syncthreads();
 
             // ---- A: this lane's point (kpt) of each of its 4 queries; exact bounding window of all corners ----
-            float him[MT_NPASS], wim[MT_NPASS], awp[MT_NPASS];
-            int hlo[MT_NPASS], wlo[MT_NPASS];
-            bool okp[MT_NPASS];
+            float him[Cfg::NPASS], wim[Cfg::NPASS], awp[Cfg::NPASS];
+            int hlo[Cfg::NPASS], wlo[Cfg::NPASS];
+            bool okp[Cfg::NPASS];
             int ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1;
 #pragma unroll
-            for (int p = 0; p < MT_NPASS; ++p) {
+            for (int p = 0; p < Cfg::NPASS; ++p) {
                 const int slot = p * MT_QPP + slot0;
                 const float2_t xy = s_loc[slot * PT + kpt];
                 awp[p] = s_aw[slot * PT + kpt];
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
             if (y1 < 0) continue;                        // no accepted point at this level (block-uniform)
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
-            if (npix > MT_WIN_MAX) {                     // block-uniform: window does not fit -> gather from global
-                gather_level_global<PT>(acc, qok, s_loc, s_aw, slot0, H, W, vl, MD);
+            if (npix > Cfg::WIN_MAX) {                     // block-uniform: window does not fit -> gather from global
+                gather_level_global<PT, Cfg>(acc, qok, s_loc, s_aw, slot0, H, W, vl, MD);
                 continue;
             }
 
@@ -240,10 +244,10 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
             }
             // the owner lane turns its point into 4 LDS byte offsets (+ this lane's channel chunk) and 4 weights while
             // the DMA is in flight; a corner that must not contribute points at the all-zero pixel
-            int o1[MT_NPASS], o2[MT_NPASS], o3[MT_NPASS], o4[MT_NPASS];
-            float w1[MT_NPASS], w2[MT_NPASS], w3[MT_NPASS], w4[MT_NPASS];
+            int o1[Cfg::NPASS], o2[Cfg::NPASS], o3[Cfg::NPASS], o4[Cfg::NPASS];
+            float w1[Cfg::NPASS], w2[Cfg::NPASS], w3[Cfg::NPASS], w4[Cfg::NPASS];
 #pragma unroll
-            for (int p = 0; p < MT_NPASS; ++p) {
+            for (int p = 0; p < Cfg::NPASS; ++p) {
                 const int hl = hlo[p], wl = wlo[p];
                 const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl;
                 const float hh = 1.f - lh, hw = 1.f - lw;
@@ -255,10 +259,10 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
                 const bool k3 = pok && hl + 1 <= H - 1 && wl >= 0;
                 const bool k4 = pok && hl + 1 <= H - 1 && wl + 1 <= W - 1;
                 const int ry0 = hl - y0, ry1 = hl + 1 - y0, rx0 = wl - x0w, rx1 = wl + 1 - x0w;
-                o1[p] = (k1 ? ry0 * ww + rx0 : MT_ZP) * 128;
-                o2[p] = (k2 ? ry0 * ww + rx1 : MT_ZP) * 128;
-                o3[p] = (k3 ? ry1 * ww + rx0 : MT_ZP) * 128;
-                o4[p] = (k4 ? ry1 * ww + rx1 : MT_ZP) * 128;
+                o1[p] = (k1 ? ry0 * ww + rx0 : Cfg::ZP) * 128;
+                o2[p] = (k2 ? ry0 * ww + rx1 : Cfg::ZP) * 128;
+                o3[p] = (k3 ? ry1 * ww + rx0 : Cfg::ZP) * 128;
+                o4[p] = (k4 ? ry1 * ww + rx1 : Cfg::ZP) * 128;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -279,13 +283,13 @@ __global__ __launch_bounds__(MT_THREADS, 2) void msda_fwd_tiled_kernel(
         }                                                                                                        \
     }
 #pragma unroll
-            for (int p = 0; p < MT_NPASS; ++p) {
+            for (int p = 0; p < Cfg::NPASS; ++p) {
                 MT_POINT(0) MT_POINT(1) MT_POINT(2) MT_POINT(3)
             }
 #undef MT_POINT
         }
 #pragma unroll
-        for (int p = 0; p < MT_NPASS; ++p)
+        for (int p = 0; p < Cfg::NPASS; ++p)
             if (qok[p]) {
                 float4_t o = {acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
                 *reinterpret_cast<float4_t *>(out + qidx[p] * D + sub * 4) = o;
@@ -302,6 +306,27 @@ bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const 
 int msda_pipe_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                      const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_pipe.hip
 
+template <typename Cfg>
+static int tiled_launch_cfg(int cus, const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                            const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st)
+{
+    const size_t lds = Cfg::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled_kernel<4, Cfg>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = (cus / 8) * 8 * Cfg::BPC;   // persistent: BPC blocks per CU
+    VLLM_LAUNCH((msda_fwd_tiled_kernel<4, Cfg>), dim3(grid), dim3(MT_THREADS), lds, st, value, shapes, lsi, loc, attw, B, S, M,
+                L, Lq, out);
+    VLLM_CHECK_LAUNCH("msda_fwd_tiled_kernel");
+    return VLLM_OK;
+}
+
+int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                       const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_tiled4.hip
+
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
@@ -313,18 +338,12 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    const size_t lds = MT_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
-    VLLM_LAUNCH((msda_fwd_tiled_kernel<4>), dim3(grid), dim3(MT_THREADS), lds, st, value, shapes, lsi, loc, attw, B, S, M, L,
-                Lq, out);
-    VLLM_CHECK_LAUNCH("msda_fwd_tiled_kernel");
     (void)P;
-    return VLLM_OK;
+    if (msda_tiled_enabled() >= 5 && (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30))   // 32-bit offsets
+        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (msda_tiled_enabled() == 4) return tiled_launch_cfg<MTCfg<8, 8, 288, 3>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (msda_tiled_enabled() == 3) return tiled_launch_cfg<MTCfg<8, 8, 288, 4>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    return tiled_launch_cfg<MTCfg<8, 16, 560, 2>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
 }
 
 }  // namespace vllm
