@@ -35,13 +35,15 @@ int vllm_abi_version(void);
 const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
-/* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel: 0 plain gather kernel,
- * 1 LDS-tiled kernel, 2 LDS-tiled + software-pipelined kernel (same results to fp32 rounding).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
- * kernel.  "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters.
- * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous
- * value or VLLM_EINVAL for an unknown name. */
+/* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel (same results to fp32 rounding):
+ * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block (default), 2 the same with 8 waves,
+ * 3 LDS-tiled kernel generation 2, 4 generation 3 (software-pipelined), 5 generation 4 with the phase clock
+ * (vllm_debug_counters).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel.  "attn_variant": bit0
+ * software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters.  Environment variables
+ * VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous value or
+ * VLLM_EINVAL for an unknown name. */
 int vllm_set_option(const char *name, int value);
-/* Diagnostics: with "msda_tiled" = 6 the LDS-tiled MSDA kernel adds per-phase shader-clock ticks (wave 0 of every block) to
+/* Diagnostics: with "msda_tiled" = 5 the LDS-tiled MSDA kernel adds per-phase shader-clock ticks (wave 0 of every block) to
  * 16 device counters; this reads them into out[0..n) and clears them.  Returns the number of counters written. */
 int vllm_debug_counters(long *out, int n);
 

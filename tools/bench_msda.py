@@ -51,10 +51,10 @@ def main():
                     t[k] = t[k] + 0.01 * torch.randn_like(t[k])
             B, S, M, D = t["value"].shape
             Lq, L, P = t["loc"].shape[1], t["loc"].shape[3], t["loc"].shape[4]
-            for dt in ("f32_tiled", "f32_gen4", "f32_gather", "bf16"):
+            for dt in ("f32_tiled", "f32_tiled_w8", "f32_gen2", "f32_gather", "bf16"):
                 v = t["value"] if dt != "bf16" else t["value"].bfloat16()
                 from visionllm_amd import _lib
-                _lib.set_option("msda_tiled", {"f32_gather": 0, "f32_tiled": 1, "f32_pipe": 2, "f32_t8x8b4": 3, "f32_t8x8b3": 4, "f32_gen4": 5}.get(dt, 1))
+                _lib.set_option("msda_tiled", {"f32_gather": 0, "f32_tiled": 1, "f32_tiled_w8": 2, "f32_gen2": 3, "f32_pipe": 4}.get(dt, 1))
                 sec = timeit(lambda: A.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["attw"], 64), a.iters)
                 ab = algorithmic_bytes(B, S, M, D, L, Lq, P, 4 if dt != "bf16" else 2)
                 gathered = B * Lq * M * L * P * 4 * D * (4 if dt != "bf16" else 2)

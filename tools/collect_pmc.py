@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KEY = {"msda_fwd": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<2>": "gemm", "gemm256_bf16_kernelILi2": "gemm"}
+KEY = {"msda_fwd_tiled4": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<2,": "gemm", "gemm256_bf16_kernelILi2": "gemm"}
 
 
 def load(d):

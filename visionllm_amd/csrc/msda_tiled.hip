@@ -330,7 +330,12 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
-    if (msda_tiled_enabled() == 2) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    const int mode = msda_tiled_enabled();
+    // generation 4 keeps pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
+    const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
+    if ((mode == 1 || mode == 2 || mode == 5) && fits32)
+        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 4) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     static int cus = 0;
     if (cus == 0) {
         hipDeviceProp_t prop;
@@ -339,10 +344,6 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
                   ? prop.multiProcessorCount : 256;
     }
     (void)P;
-    if (msda_tiled_enabled() >= 5 && (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30))   // 32-bit offsets
-        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    if (msda_tiled_enabled() == 4) return tiled_launch_cfg<MTCfg<8, 8, 288, 3>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    if (msda_tiled_enabled() == 3) return tiled_launch_cfg<MTCfg<8, 8, 288, 4>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     return tiled_launch_cfg<MTCfg<8, 16, 560, 2>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
 }
 

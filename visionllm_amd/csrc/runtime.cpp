@@ -36,7 +36,7 @@ int msda_tiled_enabled()
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
         g_msda_tiled = e ? atoi(e) : 1;
-        if (g_msda_tiled < 0 || g_msda_tiled > 6) g_msda_tiled = 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 5) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -47,7 +47,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) {
         const int old = vllm::msda_tiled_enabled();
-        if (value < 0 || value > 6) { vllm::set_error("msda_tiled must be 0..6"); return VLLM_EINVAL; }
+        if (value < 0 || value > 5) { vllm::set_error("msda_tiled must be 0..5"); return VLLM_EINVAL; }
         vllm::g_msda_tiled = value;
         return old;
     }
