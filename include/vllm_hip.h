@@ -99,6 +99,47 @@ int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int
                            double *grad_value, double *grad_loc, double *grad_attw, vllm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a13 / f2. The whole deformable-attention LAYER around the operator, for bf16 (inference-dtype) modules.
+ *
+ * Replaces the bodies of
+ *   MSDeformAttn.forward                                   visionllmv2/model/unipose/ops/modules/ms_deform_attn.py:83-145
+ *   MultiScaleDeformableAttention.forward (mmcv)           mmcv/ops/multi_scale_deform_attn.py:262-367
+ *   GroundingDinoMultiscaleDeformableAttention.forward     visionllmv2/model/grounding_dino/modeling_grounding_dino_mask_dn.py:706-784
+ * i.e. value_proj (+ key-padding zero fill), the sampling_offsets / attention_weights linears, softmax over the
+ * L*P logits of a head, the location arithmetic (2-d reference points: ref + off / (W_l, H_l); 4-d: ref_xy +
+ * off / P * ref_wh * 0.5, or the UniPose "4D normalizer" form off / (W_l, H_l) * ref_wh * 0.5), the operator and
+ * output_proj.  Activations and weights are bf16 (nn.Linear layout [out, in]); every INTERNAL tensor (value, offsets,
+ * logits, locations, weights, operator output) is kept in fp32, i.e. at or above the precision the reference has
+ * when it upcasts around the operator (ms_deform_attn.py:131-139).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct VllmMsdaLayerDesc {
+    int32_t d_model, n_heads, n_levels, n_points;
+    int32_t ref_dim;             /* last dim of reference_points: 2 or 4 */
+    int32_t use_4d_normalizer;   /* ref_dim 4 only: UniPose's use_4D_normalizer */
+    const uint16_t *value_proj_w, *value_proj_b;                  /* [C, C], [C]           (device, bf16) */
+    const uint16_t *sampling_offsets_w, *sampling_offsets_b;      /* [M*L*P*2, C], [M*L*P*2] */
+    const uint16_t *attention_weights_w, *attention_weights_b;    /* [M*L*P, C], [M*L*P] */
+    const uint16_t *output_proj_w, *output_proj_b;                /* [C, C], [C] */
+} VllmMsdaLayerDesc;
+unsigned long vllm_msda_layer_desc_sizeof(void);
+/* Bytes of device scratch vllm_msda_layer_forward needs for (B, Lq, S); negative on a bad descriptor. */
+long vllm_msda_layer_workspace_bytes(const VllmMsdaLayerDesc *desc, int B, int Lq, int S);
+/* query [B, Lq, C] bf16 (position embedding already added by the caller), reference_points [B, Lq, L, ref_dim] fp32,
+ * input_flatten [B, S, C] bf16, padding_mask [B, S] uint8 (non-zero = padded) or NULL, spatial_shapes [L, 2] /
+ * level_start_index [L] device int64 (H, W), out [B, Lq, C] bf16.  d_model % 64 == 0, d_model / n_heads % 4 == 0. */
+int vllm_msda_layer_forward(const VllmMsdaLayerDesc *desc, const uint16_t *query, const float *reference_points,
+                            const uint16_t *input_flatten, const uint8_t *padding_mask, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, int B, int Lq, int S, uint16_t *out, void *workspace,
+                            long workspace_bytes, vllm_stream_t stream);
+/* The two elementwise kernels of the layer, exposed for the parity tests:
+ * in place, offsets [R, M, L, P, 2] -> sampling locations and logits [R, M, L*P] -> softmax weights (R = B*Lq rows,
+ * reference_points [R, L, ref_dim]); and fp32 -> bf16 (round to nearest even) of n elements. */
+int vllm_msda_prep_f32(float *offsets_to_locations, float *logits_to_weights, const float *reference_points,
+                       const int64_t *spatial_shapes, long R, int M, int L, int P, int ref_dim, int use_4d_normalizer,
+                       vllm_stream_t stream);
+int vllm_f32_to_bf16(const float *src, uint16_t *dst, long n, vllm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building blocks of the ViT path (bf16 storage, fp32 accumulation).  Exposed individually so the parity
  * tests can pin every kernel against the oracle, and as bring-up hooks B4/B5 of SURVEY.md section 8b.
  * All bf16 tensors are passed as uint16_t*.
@@ -110,6 +151,9 @@ int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int
 #define VLLM_EPI_QUICK_GELU 2  /* y = z*sigmoid(1.702 z)                          (CLIP MLP) */
 #define VLLM_EPI_RESIDUAL 3    /* y = res + (x W^T + b) * scale                   (LayerScale + residual, modeling_intern_vit.py:206-208) */
 #define VLLM_EPI_EMBED 4       /* patch embedding: rows scattered past the CLS slot, + position embedding */
+#define VLLM_EPI_F32 5         /* y = x W^T + b kept in fp32: Y is float*, ldy in floats (16-byte aligned rows); `res`, if
+                                * given, is a uint8 row mask [M]: masked rows are written as zeros (the key-padding
+                                * zero-fill of the MSDA value projection) */
 /* Kernel choice is automatic (256x256 8-phase schedule for M,N >= 1024, 128x128 otherwise); OR one of these into
  * `epilogue` to force a schedule (parity tests / tuning only). */
 #define VLLM_GEMM_FORCE_128 0x100

@@ -106,3 +106,50 @@ def level_start_index(shapes):
     shapes = np.asarray(shapes, dtype=np.int64)
     areas = shapes[:, 0] * shapes[:, 1]
     return np.concatenate([[0], np.cumsum(areas)[:-1]]).astype(np.int64)
+
+
+def layer_forward(query, reference_points, input_flatten, shapes, lsi, padding_mask, params, n_heads, n_levels, n_points,
+                  use_4d_normalizer=False, dtype=np.float64):
+    """CPU restatement of the deformable-attention LAYER (test infrastructure).
+
+    Follows MSDeformAttn.forward, visionllmv2/model/unipose/ops/modules/ms_deform_attn.py:83-145 (== mmcv
+    multi_scale_deform_attn.py:318-367 == ...mask_dn.py:729-782): value_proj (:106), key-padding zero fill (:107-108),
+    sampling_offsets / attention_weights linears (:110-111), softmax over L*P (:112), locations for 2-d (:114-117) and
+    4-d reference points (:118-126), the operator (C oracle, fp64 when dtype is float64), output_proj (:144).
+    ``params`` maps value_proj / sampling_offsets / attention_weights / output_proj to (weight [out, in], bias)."""
+    q = np.asarray(query, dtype)
+    x = np.asarray(input_flatten, dtype)
+    ref = np.asarray(reference_points, dtype)
+    B, Lq, C = q.shape
+    S = x.shape[1]
+    M, L, P = n_heads, n_levels, n_points
+
+    def lin(name, t):
+        w, b = params[name]
+        return t @ np.asarray(w, dtype).T + np.asarray(b, dtype)
+
+    value = lin("value_proj", x)
+    if padding_mask is not None:
+        value = np.where(np.asarray(padding_mask, bool)[..., None], 0.0, value)
+    value = value.reshape(B, S, M, C // M)
+    off = lin("sampling_offsets", q).reshape(B, Lq, M, L, P, 2)
+    logit = lin("attention_weights", q).reshape(B, Lq, M, L * P)
+    logit = logit - logit.max(-1, keepdims=True)
+    aw = np.exp(logit)
+    aw = (aw / aw.sum(-1, keepdims=True)).reshape(B, Lq, M, L, P)
+    shp = np.asarray(shapes, dtype)
+    if ref.shape[-1] == 2:
+        normalizer = np.stack([shp[:, 1], shp[:, 0]], -1)
+        loc = ref[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    elif ref.shape[-1] == 4:
+        if use_4d_normalizer:
+            normalizer = np.stack([shp[:, 1], shp[:, 0]], -1)
+            loc = ref[:, :, None, :, None, :2] + off / normalizer[None, None, None, :, None, :] * \
+                ref[:, :, None, :, None, 2:] * 0.5
+        else:
+            loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    else:
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref.shape[-1]))
+    core = forward(np.ascontiguousarray(value), shapes, lsi, np.ascontiguousarray(loc), np.ascontiguousarray(aw))
+    return lin("output_proj", np.asarray(core, dtype)), loc, aw
+

@@ -272,3 +272,178 @@ def test_modules_match_oracle_composition():
                  level_start_index=lsi)
     torch.testing.assert_close(o3, expect, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(aw3, aw, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a13 / f2: the fused layer (vllm_msda_layer_forward) and its building blocks
+# ---------------------------------------------------------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def test_gemm_f32_epilogue_with_row_mask():
+    import ctypes
+    from visionllm_amd import _lib
+    torch.manual_seed(0)
+    Mr, N, K = 777, 160, 256
+    x, w, b = _bf(torch.randn(Mr, K, device=DEV)), _bf(torch.randn(N, K, device=DEV) * 0.1), _bf(torch.randn(N, device=DEV))
+    mask = (torch.rand(Mr, device=DEV) < 0.2).to(torch.uint8)
+    y = torch.full((Mr, N), float("nan"), device=DEV)
+    for m in (None, mask):
+        _lib.check(_lib.lib().vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), Mr, N, K, K, K, N,
+                                             _lib.EPI_F32, None, _lib.ptr(m), 0, 0, _lib.current_stream()), "gemm f32")
+        ref = x.double() @ w.double().T + b.double()
+        if m is not None:
+            ref = ref * (1 - m.double())[:, None]
+        torch.testing.assert_close(y.double(), ref, rtol=2e-5, atol=2e-4)   # fp32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("L,P,ref_dim,four_d", [(4, 4, 2, 0), (4, 4, 4, 0), (4, 4, 4, 1), (2, 4, 2, 0), (3, 4, 2, 0),
+                                               (4, 8, 4, 0), (5, 3, 4, 1), (1, 4, 2, 0)])
+def test_prep_kernel_softmax_and_locations(L, P, ref_dim, four_d):
+    from visionllm_amd import _lib
+    torch.manual_seed(L * 10 + P)
+    R, M = 301, 8
+    off = torch.randn(R, M, L, P, 2, device=DEV) * 3
+    lg = torch.randn(R, M, L * P, device=DEV) * 4
+    ref = torch.rand(R, L, ref_dim, device=DEV)
+    shapes = torch.tensor([(7 + 3 * l, 5 + 2 * l) for l in range(L)], device=DEV)
+    o, g = off.clone(), lg.clone()
+    _lib.check(_lib.lib().vllm_msda_prep_f32(_lib.ptr(o), _lib.ptr(g), _lib.ptr(ref), _lib.ptr(shapes), R, M, L, P, ref_dim,
+                                             four_d, _lib.current_stream()), "prep")
+    aw = torch.softmax(lg.double(), -1)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).double()
+    if ref_dim == 2:
+        loc = ref.double()[:, None, :, None, :] + off.double() / norm[None, None, :, None, :]
+    elif four_d:
+        loc = ref.double()[:, None, :, None, :2] + off.double() / norm[None, None, :, None, :] * \
+            ref.double()[:, None, :, None, 2:] * 0.5
+    else:
+        loc = ref.double()[:, None, :, None, :2] + off.double() / P * ref.double()[:, None, :, None, 2:] * 0.5
+    torch.testing.assert_close(g.double(), aw, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(o.double(), loc, rtol=1e-5, atol=1e-6)
+
+
+def test_f32_to_bf16_is_round_to_nearest_even():
+    from visionllm_amd import _lib
+    torch.manual_seed(0)
+    for n in (1, 3, 4, 1027, 1 << 16):
+        x = torch.randn(n, device=DEV) * 100
+        x[::7] = 1.00390625   # ties
+        y = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        _lib.check(_lib.lib().vllm_f32_to_bf16(_lib.ptr(x), _lib.ptr(y), n, _lib.current_stream()), "cvt")
+        assert torch.equal(y, x.to(torch.bfloat16))
+
+
+def _layer_case(B, shapes, Lq, ref_dim, four_d, seed, M=8, P=4, C=256, masked=True):
+    torch.manual_seed(seed)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    mod = A.MSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=P, use_4D_normalizer=bool(four_d))
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.1)
+        mod.attention_weights.bias.normal_(0, 0.5)
+        mod.value_proj.bias.normal_(0, 0.1)
+        mod.output_proj.bias.normal_(0, 0.1)
+    mod = mod.to(DEV).to(torch.bfloat16).eval()
+    Lq = S if Lq is None else Lq
+    q = _bf(torch.randn(B, Lq, C, device=DEV))
+    src = _bf(torch.randn(B, S, C, device=DEV))
+    ref = torch.rand(B, Lq, L, ref_dim, device=DEV)
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+    ss = torch.tensor(shapes, device=DEV)
+    lsi = torch.from_numpy(O.level_start_index(shapes)).to(DEV)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        mask[-1, -S // 7:] = True
+    return mod, q, ref, src, ss, lsi, mask
+
+
+def _layer_truth(mod, q, ref, src, ss, lsi, mask):
+    """fp64 oracle on the module's (bf16-valued) parameters and inputs, and the reference's own arithmetic in bf16
+    (bf16 linears / softmax / location math as the bf16 module would run them, fp32 operator: ms_deform_attn.py:131-139)."""
+    params = {n: (getattr(mod, n).weight.detach().double().cpu().numpy(), getattr(mod, n).bias.detach().double().cpu().numpy())
+              for n in ("value_proj", "sampling_offsets", "attention_weights", "output_proj")}
+    m = None if mask is None else mask.cpu().numpy()
+    truth, loc, aw = O.layer_forward(q.double().cpu().numpy(), ref.double().cpu().numpy(), src.double().cpu().numpy(),
+                                     ss.cpu().numpy(), lsi.cpu().numpy(), m, params, mod.n_heads, mod.n_levels,
+                                     mod.n_points, mod.use_4D_normalizer)
+    cm = mod.cpu()
+    with torch.no_grad():
+        qc, sc, rc = q.cpu(), src.cpu(), ref.cpu().to(torch.bfloat16)
+        B, Lq, C = qc.shape
+        S = sc.shape[1]
+        v = cm.value_proj(sc)
+        if mask is not None:
+            v = v.masked_fill(mask.cpu()[..., None], 0.0)
+        off = cm.sampling_offsets(qc).view(B, Lq, cm.n_heads, cm.n_levels, cm.n_points, 2)
+        awb = F.softmax(cm.attention_weights(qc).view(B, Lq, cm.n_heads, -1), -1).view(B, Lq, cm.n_heads, cm.n_levels,
+                                                                                      cm.n_points)
+        locb = A._sampling_locations(rc, off, ss.cpu(), cm.n_points, cm.use_4D_normalizer)
+        core = O.forward(v.view(B, S, cm.n_heads, -1).float().numpy(), ss.cpu().numpy(), lsi.cpu().numpy(),
+                         locb.float().numpy(), awb.float().numpy())
+        ref_bf16 = cm.output_proj(torch.from_numpy(core).to(torch.bfloat16)).double().numpy()
+    mod.to(DEV)
+    return truth, ref_bf16
+
+
+import torch.nn.functional as F  # noqa: E402
+
+
+@pytest.mark.parametrize("shapes,Lq,ref_dim,four_d", [
+    ([(12, 16), (6, 8), (3, 4)], 50, 2, 0),          # decoder-like: few queries, gather kernel
+    ([(12, 16), (6, 8), (3, 4)], 37, 4, 0),          # 4-d reference points (boxes)
+    ([(12, 16), (6, 8)], 64, 4, 1),                  # UniPose 4D normalizer
+    ([(72, 64), (36, 32), (18, 16), (9, 8)], None, 2, 0),   # encoder self-attention: Lq == S -> LDS-tiled operator
+])
+def test_fused_layer_vs_oracle(shapes, Lq, ref_dim, four_d):
+    mod, q, ref, src, ss, lsi, mask = _layer_case(2, shapes, Lq, ref_dim, four_d, seed=len(shapes) * 7 + ref_dim)
+    with torch.no_grad():
+        assert A.msda_layer_fused_ok(q, src, mod.value_proj, mod.sampling_offsets, mod.attention_weights, mod.output_proj)
+        out = mod(q, ref, src, ss, lsi, mask)
+        again = mod(q, ref, src, ss, lsi, mask)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, again)
+    truth, ref_bf16 = _layer_truth(mod, q, ref, src, ss, lsi, mask)
+    o = out.double().cpu().numpy()
+    rms = np.sqrt((truth ** 2).mean())
+    err = np.sqrt(((o - truth) ** 2).mean()) / rms
+    err_ref = np.sqrt(((ref_bf16 - truth) ** 2).mean()) / rms
+    # internal tensors are fp32, so we must be at least as close to the fp64 truth as the reference's bf16 arithmetic
+    assert err <= max(err_ref * 1.05, 4e-3), (err, err_ref)
+    assert np.abs(o - truth).max() <= 2e-2 * np.abs(truth).max()
+
+
+def test_fused_layer_module_flavours_and_fallbacks():
+    shapes = [(12, 16), (6, 8), (3, 4)]
+    mod, q, ref, src, ss, lsi, mask = _layer_case(2, shapes, 40, 2, 0, seed=5, C=128, M=4)
+    with torch.no_grad():
+        expect = mod(q, ref, src, ss, lsi, mask)
+        mm = A.MultiScaleDeformableAttention(embed_dims=128, num_heads=4, num_levels=3, num_points=4, dropout=0.0)
+        mm = mm.to(DEV).to(torch.bfloat16).eval()
+        mm.load_state_dict(mod.state_dict())
+        o2 = mm(q.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref,
+                spatial_shapes=ss, level_start_index=lsi)
+        torch.testing.assert_close(o2.permute(1, 0, 2).float(), (expect + q).float(), rtol=1e-2, atol=1e-2)
+
+        class Cfg:
+            d_model, num_feature_levels, disable_custom_kernels = 128, 3, False
+        gd = A.GroundingDinoMultiscaleDeformableAttention(Cfg(), 4, 4).to(DEV).to(torch.bfloat16).eval()
+        gd.load_state_dict(mod.state_dict())
+        o3, aw3 = gd(q, attention_mask=~mask, encoder_hidden_states=src, reference_points=ref, spatial_shapes=ss,
+                     level_start_index=lsi)
+        assert aw3 is None and torch.equal(o3, expect)
+        # asking for the attention weights takes the composed path (same result to bf16 rounding, weights returned)
+        o4, aw4 = gd(q, attention_mask=~mask, encoder_hidden_states=src, reference_points=ref, spatial_shapes=ss,
+                     level_start_index=lsi, output_attentions=True)
+        assert aw4 is not None and aw4.shape == (2, 40, 4, 3, 4)
+        torch.testing.assert_close(o4.float(), expect.float(), rtol=3e-2, atol=3e-2)
+    # fp32 modules and training keep the composed path
+    assert not A.msda_layer_fused_ok(q.float(), src.float(), mod.value_proj)
+    assert not A.msda_layer_fused_ok(q, src, mod.value_proj)          # grad enabled + trainable parameters
+    with pytest.raises(ValueError):
+        A.msda_layer_forward(q, ref[..., :1].expand(-1, -1, -1, 3), src, ss, lsi, None, mod.value_proj, mod.sampling_offsets,
+                             mod.attention_weights, mod.output_proj, 4, 3, 4)
+

@@ -126,14 +126,22 @@ class VllmBridgeDesc(ctypes.Structure):
                [("ln_eps", ctypes.c_float), ("ln_w", _P), ("ln_b", _P), ("w", _P * 4), ("b", _P * 4)]
 
 
+class VllmMsdaLayerDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("d_model", "n_heads", "n_levels", "n_points", "ref_dim",
+                                              "use_4d_normalizer")] + \
+               [(n, _P) for n in ("value_proj_w", "value_proj_b", "sampling_offsets_w", "sampling_offsets_b",
+                                  "attention_weights_w", "attention_weights_b", "output_proj_w", "output_proj_b")]
+
+
 def check_struct_layouts():
     L = lib()
+    assert ctypes.sizeof(VllmMsdaLayerDesc) == L.vllm_msda_layer_desc_sizeof(), "VllmMsdaLayerDesc layout mismatch"
     assert ctypes.sizeof(VllmVitDesc) == L.vllm_vit_desc_sizeof(), "VllmVitDesc layout mismatch"
     assert ctypes.sizeof(VllmVitLayer) == L.vllm_vit_layer_sizeof(), "VllmVitLayer layout mismatch"
     assert ctypes.sizeof(VllmBridgeDesc) == L.vllm_bridge_desc_sizeof(), "VllmBridgeDesc layout mismatch"
 
 
-EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_EMBED = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_EMBED, EPI_F32 = 0, 1, 2, 3, 4, 5
 ARCH_INTERNVIT, ARCH_CLIP = 0, 1
 BRIDGE_LINEAR, BRIDGE_MLP_GELU, BRIDGE_INTERNVL_MLP = 0, 1, 2
 

@@ -137,7 +137,7 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     VLLM_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     VLLM_REQUIRE(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
     VLLM_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0 && a.ldy % 4 == 0 && aligned16(a.X) && aligned16(a.W) &&
-                     (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0,
+                     (reinterpret_cast<uintptr_t>(a.Y) & (epi == EPI_F32 ? 15u : 7u)) == 0,
                  "gemm: operands must be 16-byte aligned with row strides multiple of 8 elements");
     VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
     VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
@@ -157,6 +157,7 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     case EPI_QUICK_GELU: L(EPI_QUICK_GELU); break;
     case EPI_RESIDUAL: L(EPI_RESIDUAL); break;
     case EPI_EMBED: L(EPI_EMBED); break;
+    case EPI_F32: L(EPI_F32); break;
     default: set_error("gemm: unknown epilogue %d", epi); return VLLM_EINVAL;
     }
 #undef L

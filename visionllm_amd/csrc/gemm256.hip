@@ -240,6 +240,7 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     case EPI_QUICK_GELU: L(EPI_QUICK_GELU); break;
     case EPI_RESIDUAL: L(EPI_RESIDUAL); break;
     case EPI_EMBED: L(EPI_EMBED); break;
+    case EPI_F32: L(EPI_F32); break;
     default: set_error("gemm256: unknown epilogue %d", epi); return VLLM_EINVAL;
     }
 #undef L

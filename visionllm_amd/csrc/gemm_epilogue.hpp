@@ -70,6 +70,13 @@ __device__ __forceinline__ void epi_store(const GemmArgs &a, int m, int n, const
         const uint2_t pp = *reinterpret_cast<const uint2_t *>(a.res + (size_t)(1 + p) * a.ldr + n);
         v[0] += bf16lo_to_f32(pp.x); v[1] += bf16hi_to_f32(pp.x); v[2] += bf16lo_to_f32(pp.y); v[3] += bf16hi_to_f32(pp.y);
     }
+    if (EPI == EPI_F32) {   // fp32 result (Y is float*, ldy in floats); `res` = optional uint8 row mask -> zero rows
+        const uint8_t *mask = reinterpret_cast<const uint8_t *>(a.res);
+        const bool dead = mask && mask[m] != 0;
+        const float4_t o4 = {dead ? 0.f : v[0], dead ? 0.f : v[1], dead ? 0.f : v[2], dead ? 0.f : v[3]};
+        *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(a.Y) + orow * a.ldy + n) = o4;
+        return;
+    }
     uint2_t o;
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);

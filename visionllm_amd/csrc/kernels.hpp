@@ -10,6 +10,7 @@ enum GemmEpilogue : int {
     EPI_QUICK_GELU = VLLM_EPI_QUICK_GELU,
     EPI_RESIDUAL = VLLM_EPI_RESIDUAL,
     EPI_EMBED = VLLM_EPI_EMBED,
+    EPI_F32 = VLLM_EPI_F32,
 };
 
 struct GemmArgs {

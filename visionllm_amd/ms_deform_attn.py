@@ -17,6 +17,7 @@ The compute is libvllm_hip.so (visionllm_amd/csrc/msda.hip).  Like the reference
 reference modules we do NOT silently fall back to a pure-torch path (modeling_ov_grounding_dino_mask_dn.py:777-779
 would mask a broken kernel).
 """
+import ctypes
 import math
 import warnings
 
@@ -229,6 +230,55 @@ def _sampling_locations(reference_points, sampling_offsets, spatial_shapes, n_po
         "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
 
 
+def msda_layer_fused_ok(query, input_flatten, *linears):
+    """The fused HIP layer serves inference-dtype (bf16) modules on the GPU; anything else keeps the composed path."""
+    if not (query.is_cuda and query.dtype == torch.bfloat16 and input_flatten.dtype == torch.bfloat16):
+        return False
+    if torch.is_grad_enabled() and any(p.requires_grad for lin in linears for p in lin.parameters()):
+        return False   # training differentiates through the composed path (autograd Function around the operator)
+    d_model = query.shape[-1]
+    return d_model % 64 == 0 and all(lin.weight.dtype == torch.bfloat16 and lin.bias is not None for lin in linears)
+
+
+def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask,
+                       value_proj, sampling_offsets, attention_weights, output_proj, n_heads, n_levels, n_points,
+                       use_4d_normalizer=False):
+    """value_proj -> offsets / weights linears -> softmax -> locations -> operator -> output_proj in ONE C call
+    (vllm_msda_layer_forward; replaces ms_deform_attn.py:102-145 / ...mask_dn.py:729-782 for bf16 modules).
+    query [B, Lq, C] bf16 (position embedding already added), reference_points [B, Lq, L, 2|4], input_flatten [B, S, C]."""
+    B, Lq, C = query.shape
+    S = input_flatten.shape[1]
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]))
+    L = _lib.lib()
+    desc = _lib.VllmMsdaLayerDesc()
+    desc.d_model, desc.n_heads, desc.n_levels, desc.n_points = C, n_heads, n_levels, n_points
+    desc.ref_dim, desc.use_4d_normalizer = reference_points.shape[-1], int(bool(use_4d_normalizer))
+    keep = []
+    for name, lin in (("value_proj", value_proj), ("sampling_offsets", sampling_offsets),
+                      ("attention_weights", attention_weights), ("output_proj", output_proj)):
+        w, b = lin.weight.detach().contiguous(), lin.bias.detach().to(torch.bfloat16).contiguous()
+        keep += [w, b]
+        setattr(desc, name + "_w", w.data_ptr())
+        setattr(desc, name + "_b", b.data_ptr())
+    q = query.contiguous()
+    x = input_flatten.contiguous()
+    ref = reference_points.to(torch.float32).contiguous()
+    shapes = spatial_shapes.to(device=q.device, dtype=torch.int64).contiguous()
+    lsi = level_start_index.to(device=q.device, dtype=torch.int64).contiguous()
+    mask = None if padding_mask is None else padding_mask.to(torch.uint8).contiguous()
+    nbytes = L.vllm_msda_layer_workspace_bytes(ctypes.byref(desc), B, Lq, S)
+    if nbytes < 0:
+        _lib.check(-1, "vllm_msda_layer_workspace_bytes")
+    ws = _lib.workspace(q.device, nbytes)
+    out = torch.empty_like(q)
+    _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
+                                         _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
+                                         ws.numel(), _lib.current_stream(q.device)), "vllm_msda_layer_forward")
+    return out
+
+
 def _msda_apply_fp32(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
     """The reference upcasts to fp32 around the op (ms_deform_attn.py:131-139; ...mask_dn.py:764-766)."""
     dtype = value.dtype
@@ -269,6 +319,12 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        if msda_layer_fused_ok(query, input_flatten, self.value_proj, self.sampling_offsets, self.attention_weights,
+                               self.output_proj):   # bf16 inference: the whole layer in one native call
+            return msda_layer_forward(query, reference_points, input_flatten, input_spatial_shapes,
+                                      input_level_start_index, input_padding_mask, self.value_proj,
+                                      self.sampling_offsets, self.attention_weights, self.output_proj, self.n_heads,
+                                      self.n_levels, self.n_points, self.use_4D_normalizer)
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
@@ -327,6 +383,15 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
         assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == num_value
+        if msda_layer_fused_ok(query, value, self.value_proj, self.sampling_offsets, self.attention_weights,
+                               self.output_proj):
+            output = msda_layer_forward(query, reference_points, value, spatial_shapes, level_start_index,
+                                        key_padding_mask, self.value_proj, self.sampling_offsets,
+                                        self.attention_weights, self.output_proj, self.num_heads, self.num_levels,
+                                        self.num_points)
+            if not self.batch_first:
+                output = output.permute(1, 0, 2)
+            return self.dropout(output) + identity
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -387,6 +452,15 @@ class GroundingDinoMultiscaleDeformableAttention(nn.Module):
         if (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() != sequence_length:
             raise ValueError(
                 "Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
+        if not output_attentions and msda_layer_fused_ok(hidden_states, encoder_hidden_states, self.value_proj,
+                                                         self.sampling_offsets, self.attention_weights,
+                                                         self.output_proj):
+            # (the attention weights stay inside the fused call; ask for output_attentions to get them)
+            output = msda_layer_forward(hidden_states, reference_points, encoder_hidden_states, spatial_shapes,
+                                        level_start_index, None if attention_mask is None else ~attention_mask,
+                                        self.value_proj, self.sampling_offsets, self.attention_weights,
+                                        self.output_proj, self.n_heads, self.n_levels, self.n_points)
+            return output, None
         value = self.value_proj(encoder_hidden_states)
         if attention_mask is not None:
             value = value.masked_fill(~attention_mask[..., None], float(0))
