@@ -140,6 +140,22 @@ int vllm_msda_prep_f32(float *offsets_to_locations, float *logits_to_weights, co
 int vllm_f32_to_bf16(const float *src, uint16_t *dst, long n, vllm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * f3. DCNv3 forward (InternImage det backbone).
+ *
+ * Replaces:  dcnv3_forward   visionllmv2/model/ops_dcnv3/src/dcnv3.h:20-39, src/cuda/dcnv3_cuda.cu:20-80
+ *            (kernel src/cuda/dcnv3_im2col_cuda.cuh:217-278; Python caller functions/dcnv3_func.py:39-43).
+ * input [N, H, W, G*C], offset [N, Ho, Wo, G*kh*kw*2] (x, y pairs, kernel_w-outer / kernel_h-inner point order),
+ * mask [N, Ho, Wo, G*kh*kw], out [N, Ho, Wo, G*C]; Ho = (H + 2*ph - (dh*(kh-1)+1)) / sh + 1 (likewise Wo).  All device,
+ * contiguous.  im2col_step of the reference is a batching detail of its launch loop and has no counterpart (one launch).
+ * ------------------------------------------------------------------------------------------------ */
+int vllm_dcnv3_forward_f32(const float *input, const float *offset, const float *mask, int N, int H, int W, int G, int C,
+                           int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float offset_scale, float *out,
+                           vllm_stream_t stream);
+int vllm_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, int N, int H, int W, int G, int C,
+                           int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, double offset_scale, double *out,
+                           vllm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building blocks of the ViT path (bf16 storage, fp32 accumulation).  Exposed individually so the parity
  * tests can pin every kernel against the oracle, and as bring-up hooks B4/B5 of SURVEY.md section 8b.
  * All bf16 tensors are passed as uint16_t*.

@@ -95,6 +95,40 @@ def gen_msda():
     case("odd_channels", 1, 3, 5, 19, [(5, 6), (3, 3)], 2, 13, "stress")
 
 
+def gen_dcnv3():
+    """DCNv3 forward: the reference's pure-PyTorch twin on the inputs of its own test (ops_dcnv3/test.py:19-66, seed 3:
+    N=2, 8x8, M=4, D=16, 3x3, offset_scale 2, pad 1) plus strided / dilated / non-square cases."""
+    glb = {"torch": torch, "F": F}
+    fns = ast_extract(f"{REF}/visionllmv2/model/ops_dcnv3/functions/dcnv3_func.py",
+                      ["_get_reference_points", "_generate_dilation_grids", "dcnv3_core_pytorch"], glb)
+    glb.update(fns)
+    core = fns["dcnv3_core_pytorch"]
+
+    def case(name, N, H, W, M, D, kh, kw, stride, pad_h, pad_w, dil, offset_scale, seed, off_mag=10.0):
+        torch.manual_seed(seed)
+        Ho = (H + 2 * pad_h - (dil * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad_w - (dil * (kw - 1) + 1)) // stride + 1
+        P = kh * kw
+        inp = torch.rand(N, H, W, M * D) * 0.01
+        offset = torch.rand(N, Ho, Wo, M * P * 2) * off_mag
+        mask = torch.rand(N, Ho, Wo, M, P) + 1e-5
+        mask /= mask.sum(-1, keepdim=True)
+        mask = mask.reshape(N, Ho, Wo, M * P)
+        out64 = core(inp.double(), offset.double(), mask.double(), kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D,
+                     offset_scale).detach()
+        out32 = core(inp, offset, mask, kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D, offset_scale).detach()
+        np.savez_compressed(os.path.join(OUT, f"dcnv3_{name}.npz"), input=inp.numpy(), offset=offset.numpy(),
+                            mask=mask.numpy(), out_f32=out32.numpy(), out_f64=out64.numpy(),
+                            params=np.array([kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D], dtype=np.int64),
+                            offset_scale=np.array(offset_scale), torch_version=np.array(torch.__version__))
+        print(f"dcnv3_{name}: out {tuple(out64.shape)} f64[0,0,0,:3]={out64[0, 0, 0, :3].tolist()}")
+
+    case("kat_seed3", 2, 8, 8, 4, 16, 3, 3, 1, 1, 1, 1, 2.0, 3)
+    case("stride2_dil2", 2, 11, 9, 2, 8, 3, 3, 2, 2, 2, 2, 1.0, 21, off_mag=3.0)
+    # (the twin pads W by pad_h and H by pad_w, dcnv3_func.py:129-131, so it only works for pad_h == pad_w)
+    case("k5x3_odd_channels", 1, 7, 10, 3, 5, 5, 3, 1, 1, 1, 1, 0.5, 22, off_mag=4.0)
+
+
 # --------------------------------------------------------------------------------------------------
 def load_intern_vit():
     import transformers.activations, transformers.modeling_outputs, transformers.modeling_utils  # noqa: F401 (before the stub)
@@ -246,6 +280,7 @@ def gen_tiling():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_msda()
+    gen_dcnv3()
     gen_intern_vit()
     gen_clip()
     gen_bridge()

@@ -1,0 +1,110 @@
+"""DCNv3 forward on the GPU (libvllm_hip.so through the C ABI) against the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dcnv3 as O
+from visionllm_amd import dcnv3 as A
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CASES = ["dcnv3_kat_seed3.npz", "dcnv3_stride2_dil2.npz", "dcnv3_k5x3_odd_channels.npz"]
+
+
+def _args(g):
+    kh, kw, sh, sw, ph, pw, dh, dw, M, Dc = [int(v) for v in g["params"]]
+    return (kh, kw, sh, sw, ph, pw, dh, dw, M, Dc, float(g["offset_scale"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_vs_reference_golden(name):
+    g = load_golden(name)
+    a = _args(g)
+    t = lambda k, dt: torch.from_numpy(g[k]).to(dt).to(DEV)
+    o64 = A.dcnv3_forward(t("input", torch.float64), t("offset", torch.float64), t("mask", torch.float64), *a, 2)
+    np.testing.assert_allclose(o64.cpu().numpy(), g["out_f64"], rtol=1e-5, atol=1e-8)    # test.py:50 (double)
+    o32 = A.DCNv3Function.apply(t("input", torch.float32), t("offset", torch.float32), t("mask", torch.float32), *a, 2)
+    np.testing.assert_allclose(o32.cpu().numpy(), g["out_f32"], rtol=1e-2, atol=1e-3)    # test.py:77 (float)
+    # fp64 kernel against the fp64 C oracle: same arithmetic, only contraction may differ
+    ref = O.forward(g["input"].astype(np.float64), g["offset"].astype(np.float64), g["mask"].astype(np.float64), *a)
+    np.testing.assert_allclose(o64.cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("N,H,W,G,C,k,s,p,d,scale", [
+    (2, 56, 56, 4, 16, 3, 1, 1, 1, 1.0),     # InternImage stage-1-like (vector path: C % 4 == 0)
+    (1, 30, 41, 6, 20, 3, 2, 1, 1, 2.0),     # strided, ragged map
+    (2, 17, 13, 3, 7, 5, 1, 2, 1, 0.7),      # scalar path (C % 4 != 0), 5x5
+    (1, 9, 9, 2, 8, 3, 1, 2, 2, 1.5),        # dilation 2
+    (3, 4, 5, 1, 4, 1, 1, 0, 1, 1.0),        # 1x1 kernel
+])
+def test_forward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
+    rng = np.random.default_rng(N * 100 + H)
+    Ho, Wo = O.out_size(H, W, k, k, s, s, p, p, d, d)
+    inp = rng.standard_normal((N, H, W, G * C)).astype(np.float32)
+    off = (rng.standard_normal((N, Ho, Wo, G * k * k * 2)) * 2.5).astype(np.float32)   # many samples leave the map
+    msk = rng.random((N, Ho, Wo, G * k * k)).astype(np.float32)
+    out = A.dcnv3_forward(torch.from_numpy(inp).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(msk).to(DEV),
+                          k, k, s, s, p, p, d, d, G, C, scale)
+    ref = O.forward(inp, off, msk, k, k, s, s, p, p, d, d, G, C, scale)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    # the reference's CPU path (grid_sample twin) agrees too (pad_h == pad_w)
+    tw = O.core_pytorch_twin(torch.from_numpy(inp), torch.from_numpy(off), torch.from_numpy(msk), k, k, s, s, p, p, d, d, G, C,
+                             scale).numpy()
+    np.testing.assert_allclose(out.cpu().numpy(), tw, rtol=1e-3, atol=1e-4)
+
+
+def test_nonfinite_data_and_locations_do_not_leak():
+    N, H, W, G, C, k = 1, 6, 6, 2, 4, 3
+    inp = torch.randn(N, H, W, G * C)
+    off = torch.zeros(N, H, W, G * k * k * 2)
+    off[0, 0, 0, :4] = torch.tensor([float("nan"), 0.0, float("inf"), -float("inf")])   # rejected points
+    msk = torch.full((N, H, W, G * k * k), 1.0 / 9)
+    ref = O.forward(inp.numpy(), off.numpy(), msk.numpy(), k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0)
+    assert np.isfinite(ref).all()
+    out = A.dcnv3_forward(inp.to(DEV), off.to(DEV), msk.to(DEV), k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    # NaN pixels that no accepted corner touches: the border ring is only reached through clamped addresses
+    inp2 = inp.clone()
+    off2 = torch.full_like(off, 100.0)                       # every sample far outside -> nothing contributes
+    inp2[:] = float("nan")
+    out2 = A.dcnv3_forward(inp2.to(DEV), off2.to(DEV), msk.to(DEV), k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0)
+    assert torch.equal(out2, torch.zeros_like(out2))
+
+
+def test_errors_and_module():
+    x = torch.randn(2, 8, 8, 32)
+    with pytest.raises(RuntimeError, match="Not implement on cpu"):
+        A.dcnv3_forward(x, torch.zeros(2, 8, 8, 72), torch.zeros(2, 8, 8, 36), 3, 3, 1, 1, 1, 1, 1, 1, 4, 8, 1.0)
+    xg = x.to(DEV)
+    with pytest.raises(RuntimeError, match="wont match"):
+        A.dcnv3_forward(xg, torch.zeros(2, 8, 8, 72, device=DEV), torch.zeros(2, 8, 8, 36, device=DEV), 3, 3, 1, 1, 1, 1, 1, 1, 4,
+                        7, 1.0)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        A.dcnv3_forward(torch.randn(3, 8, 8, 32, device=DEV), torch.zeros(3, 8, 8, 72, device=DEV),
+                        torch.zeros(3, 8, 8, 36, device=DEV), 3, 3, 1, 1, 1, 1, 1, 1, 4, 8, 1.0, 2)
+    with pytest.raises(ValueError, match="divisible by group"):
+        A.DCNv3(channels=30, group=4)
+    torch.manual_seed(0)
+    mod = A.DCNv3(channels=32, group=4, offset_scale=1.5, center_feature_scale=True).to(DEV).eval()
+    with torch.no_grad():
+        mod.offset.weight.normal_(0, 0.3)
+        mod.mask.weight.normal_(0, 0.3)
+        mod.center_feature_scale_proj_weight.normal_(0, 0.3)
+        y = mod(xg)
+        # the same module with the sampling core replaced by the oracle
+        x1 = mod.dw_conv(xg.permute(0, 3, 1, 2))
+        off = mod.offset(x1)
+        msk = torch.softmax(mod.mask(x1).reshape(2, 8, 8, 4, -1), -1).reshape(2, 8, 8, -1)
+        xp = mod.input_proj(xg)
+        core = torch.from_numpy(O.forward(xp.cpu().numpy(), off.cpu().numpy(), msk.cpu().numpy(), 3, 3, 1, 1, 1, 1, 1, 1, 4, 8,
+                                          1.5)).to(DEV)
+        cfs = torch.sigmoid(torch.nn.functional.linear(x1, mod.center_feature_scale_proj_weight,
+                                                       mod.center_feature_scale_proj_bias))
+        cfs = cfs[..., None].repeat(1, 1, 1, 1, 8).flatten(-2)
+        expect = mod.output_proj(core * (1 - cfs) + xp * cfs)
+    torch.testing.assert_close(y, expect, rtol=1e-4, atol=1e-4)
+    assert sorted(k for k in mod.state_dict() if "dw_conv" not in k) == sorted([
+        "center_feature_scale_proj_bias", "center_feature_scale_proj_weight", "input_proj.bias", "input_proj.weight",
+        "mask.bias", "mask.weight", "offset.bias", "offset.weight", "output_proj.bias", "output_proj.weight"])

@@ -1,0 +1,44 @@
+"""DCNv3 oracle (oracle/dcnv3_oracle.c + the torch twin) against golden vectors produced by RUNNING the reference's
+dcnv3_core_pytorch on its own test inputs (oracle/gen_golden.py: gen_dcnv3; ops_dcnv3/test.py:19-66, seed 3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dcnv3 as D
+
+CASES = ["dcnv3_kat_seed3.npz", "dcnv3_stride2_dil2.npz", "dcnv3_k5x3_odd_channels.npz"]
+
+
+def _args(g):
+    kh, kw, sh, sw, ph, pw, dh, dw, M, Dc = [int(v) for v in g["params"]]
+    return (kh, kw, sh, sw, ph, pw, dh, dw, M, Dc, float(g["offset_scale"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_oracle_matches_reference_twin(name):
+    g = load_golden(name)
+    a = _args(g)
+    o64 = D.forward(g["input"].astype(np.float64), g["offset"].astype(np.float64), g["mask"].astype(np.float64), *a)
+    # the reference's own tolerance for CUDA kernel vs twin in double (test.py:50: torch.allclose defaults); the twin builds
+    # its reference points in float32 (dcnv3_func.py:66-90), so it is not more accurate than that
+    np.testing.assert_allclose(o64, g["out_f64"], rtol=1e-5, atol=1e-8)
+    o32 = D.forward(g["input"], g["offset"], g["mask"], *a)
+    np.testing.assert_allclose(o32, g["out_f32"], rtol=1e-2, atol=1e-3)   # test.py:77 (float)
+    np.testing.assert_allclose(o32, g["out_f64"], rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_torch_twin_restatement_is_the_reference_twin(name):
+    g = load_golden(name)
+    a = _args(g)
+    t = lambda k: torch.from_numpy(g[k]).double()
+    out = D.core_pytorch_twin(t("input"), t("offset"), t("mask"), *a).numpy()
+    np.testing.assert_allclose(out, g["out_f64"], rtol=0, atol=1e-15)
+
+
+def test_reference_known_answer_values():
+    """First output values of the reference twin on the seed-3 inputs of ops_dcnv3/test.py (fp64)."""
+    g = load_golden("dcnv3_kat_seed3.npz")
+    np.testing.assert_allclose(g["out_f64"][0, 0, 0, :3],
+                               [0.0003553824683531446, 0.0004284441152049652, 0.00037868138803360803], rtol=1e-12)
