@@ -107,6 +107,33 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     close(ys[0][:257], ref, 1e-2, "256 kernel vs fp32")
 
 
+@pytest.mark.parametrize("epi", [0, 2, 3])
+@pytest.mark.parametrize("force,M,N", [(0x200, 700, 1024), (0x300, 23080, 1024), (0x200, 513, 2056)])
+def test_gemm256_epilogue_paths_agree(epi, force, M, N):
+    """8-phase kernel: the LDS-transposed epilogue (row-contiguous 16-byte stores) and the direct one are bit-identical,
+    including ragged M / N edges (N = 2056: last tile 8 columns wide)."""
+    K = 256
+    torch.manual_seed(M + N + epi)
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    ls = bf(0.1 + 0.05 * torch.randn(N, device=DEV))
+    res = bf(torch.randn(M, N, device=DEV))
+    ys = []
+    try:
+        for mode in (0, 1, 2):
+            _lib.set_option("gemm_direct_store", mode)
+            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi | force,
+                                                 P(ls) if epi == 3 else None, P(res) if epi == 3 else None, N, 0, stream()))
+            ys.append(y)
+    finally:
+        _lib.set_option("gemm_direct_store", 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ys[0].float()).all()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+
+
 def test_gemm_rejects_bad_shapes():
     x = bf(torch.zeros(4, 100, device=DEV))
     with pytest.raises(RuntimeError):

@@ -182,6 +182,47 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 
     // ---- epilogue ----
+    // bf16 outputs leave through LDS: the accumulator layout gives a wave store of 16 rows x 32 contiguous bytes
+    // (11.1 us per 32 MB round of tiles, tools/probes/store_pattern.hip); re-read row-wise the tile leaves as 16-byte
+    // lane stores, 512 contiguous bytes per row (7.1 us).  The pipeline's LDS is free by now; rows are padded to 528 B.
+    constexpr int OPITCH = 528;
+    const bool via_lds = !a.direct_store && EPI != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
+    if (via_lds) {
+        __builtin_amdgcn_s_barrier();   // every wave is out of the main loop: no fragment read of the ring is pending
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;
+                const int n = n0 + nl;
+                const bool nok = n < a.N;
+                const EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int ml = qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr;
+                    const int m = m0 + ml;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (nok && m < a.M) epi_value<EPI>(a, m, n, acc[q][i][j], cols, v);
+                    uint2_t o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2_t *>(smem + ml * OPITCH + nl * 2) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        const int t = threadIdx.x, c8 = (t & 31) * 8;   // 32 lanes x 16 B = one 512-byte tile row
+#pragma unroll 4
+        for (int p = 0; p < BM_ / 16; ++p) {
+            const int ml = p * 16 + (t >> 5), m = m0 + ml, n = n0 + c8;
+            if (m < a.M && n < a.N) {
+                const uint4_t o = *reinterpret_cast<const uint4_t *>(smem + ml * OPITCH + c8 * 2);
+                *reinterpret_cast<uint4_t *>(a.Y + epi_out_row<EPI>(a, m) * a.ldy + n) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int qi = q >> 1, qj = q & 1;
@@ -222,8 +263,12 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     long tiles;
     if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
     else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;
+    // automatic: the LDS-transposed epilogue pays when a launch is only a few rounds of tiles (every CU stores at the
+    // same time: proj -11 %, 4096^3 -3 %); with many rounds the blocks drift apart and the direct stores of one hide
+    // behind the main loops of the others (fc1: +1.5 % through LDS)
+    if (a.direct_store == 2) a.direct_store = tiles > 3L * cus ? 1 : 0;
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
-    const size_t lds = 2 * G2_STAGE;   // 128 KiB
+    const size_t lds = 256 * 528;      // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB)
     static bool attr_set = false;
     if (!attr_set) {
 #define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

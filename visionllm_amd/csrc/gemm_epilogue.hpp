@@ -47,13 +47,12 @@ __device__ __forceinline__ EpiCols epi_cols(const GemmArgs &a, int n)
     return c;
 }
 
+// Final fp32 values of features n .. n+3 of token m (bias, activation, LayerScale + residual, position embedding).
 template <int EPI, typename ACC4>
-__device__ __forceinline__ void epi_store(const GemmArgs &a, int m, int n, const ACC4 &acc, const EpiCols &c)
+__device__ __forceinline__ void epi_value(const GemmArgs &a, int m, int n, const ACC4 &acc, const EpiCols &c, float (&v)[4])
 {
-    float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = acc[r] + c.bia[r];
-    size_t orow = (size_t)m;
     if (EPI == EPI_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -66,10 +65,28 @@ __device__ __forceinline__ void epi_store(const GemmArgs &a, int m, int n, const
         v[2] = bf16lo_to_f32(rr.y) + v[2] * c.scl[2]; v[3] = bf16hi_to_f32(rr.y) + v[3] * c.scl[3];
     } else if (EPI == EPI_EMBED) {
         const int img = m / a.P, p = m - img * a.P;
-        orow = (size_t)img * (a.P + 1) + 1 + p;
         const uint2_t pp = *reinterpret_cast<const uint2_t *>(a.res + (size_t)(1 + p) * a.ldr + n);
         v[0] += bf16lo_to_f32(pp.x); v[1] += bf16hi_to_f32(pp.x); v[2] += bf16lo_to_f32(pp.y); v[3] += bf16hi_to_f32(pp.y);
     }
+}
+
+// Output row of GEMM row m (the patch-embedding epilogue scatters past the CLS slot of every image).
+template <int EPI>
+__device__ __forceinline__ size_t epi_out_row(const GemmArgs &a, int m)
+{
+    if (EPI == EPI_EMBED) {
+        const int img = m / a.P, p = m - img * a.P;
+        return (size_t)img * (a.P + 1) + 1 + p;
+    }
+    return (size_t)m;
+}
+
+template <int EPI, typename ACC4>
+__device__ __forceinline__ void epi_store(const GemmArgs &a, int m, int n, const ACC4 &acc, const EpiCols &c)
+{
+    float v[4];
+    epi_value<EPI>(a, m, n, acc, c, v);
+    const size_t orow = epi_out_row<EPI>(a, m);
     if (EPI == EPI_F32) {   // fp32 result (Y is float*, ldy in floats); `res` = optional uint8 row mask -> zero rows
         const uint8_t *mask = reinterpret_cast<const uint8_t *>(a.res);
         const bool dead = mask && mask[m] != 0;

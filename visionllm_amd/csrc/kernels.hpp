@@ -27,8 +27,10 @@ struct GemmArgs {
     int xP;                 // >0: X is [n, 1+xP, K] and row m reads X row m + m/xP + 1 (CLS rows skipped)
     int variant;            // 0 auto, 1 force 128x128 kernel, 2 force 256x256 8-phase kernel (tuning / tests)
     int variant256;         // 8-phase kernel block rows: 0 auto, 3 -> 192, 4 -> 256
+    int direct_store;       // 8-phase epilogue: 0 through LDS, 1 straight from the accumulator layout, 2 automatic
 };
 
+int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
 int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
@@ -41,7 +43,7 @@ inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint1
 {
     GemmArgs a;
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
-    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP; a.variant = gemm_variant_override(); a.variant256 = 0;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     return gemm_bf16_launch(epi, a, st);
 }
 

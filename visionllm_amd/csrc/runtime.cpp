@@ -13,7 +13,16 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static int g_gemm_variant = -1, g_msda_tiled = -1, g_attn_variant = -1;
+static int g_gemm_variant = -1, g_msda_tiled = -1, g_attn_variant = -1, g_gemm_direct = -1;
+int gemm_direct_store()
+{
+    if (g_gemm_direct < 0) {   // 0 through LDS, 1 direct, 2 automatic (default)
+        const char *e = getenv("VLLM_GEMM_DIRECT_STORE");
+        g_gemm_direct = e ? atoi(e) : 2;
+        if (g_gemm_direct < 0 || g_gemm_direct > 2) g_gemm_direct = 2;
+    }
+    return g_gemm_direct;
+}
 int attn_variant()
 {
     if (g_attn_variant < 0) {
@@ -51,6 +60,7 @@ extern "C" int vllm_set_option(const char *name, int value)
         vllm::g_msda_tiled = value;
         return old;
     }
+    if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 15; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
