@@ -158,6 +158,19 @@ int vllm_dcnv3_forward_f64(const double *input, const double *offset, const doub
                            vllm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * f4. Region-encoder point sampling.
+ *
+ * Replaces: point_sample (F.grid_sample(input, 2*coords-1), bilinear, zeros padding, align_corners=False) and the masked
+ * mean over a region's sampled points, visionllmv2/model/region_encoder.py:24-47, 127-141.
+ * input [N, C, H, W] fp32 (contiguous NCHW), coords [N, P, 2] (x, y) in [0, 1], valid [N, P] uint8.
+ * ------------------------------------------------------------------------------------------------ */
+int vllm_point_sample_f32(const float *input, const float *coords, int N, int C, int H, int W, int P, float *out /* [N,C,P] */,
+                          vllm_stream_t stream);
+/* out[n, c] = sum_p valid * sample / sum_p valid, 0 for a region without points ((x / 0).nan_to_num() of the reference). */
+int vllm_point_sample_mean_f32(const float *input, const float *coords, const uint8_t *valid, int N, int C, int H, int W, int P,
+                               float *out /* [N,C] */, vllm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building blocks of the ViT path (bf16 storage, fp32 accumulation).  Exposed individually so the parity
  * tests can pin every kernel against the oracle, and as bring-up hooks B4/B5 of SURVEY.md section 8b.
  * All bf16 tensors are passed as uint16_t*.

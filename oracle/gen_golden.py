@@ -129,6 +129,27 @@ def gen_dcnv3():
     case("k5x3_odd_channels", 1, 7, 10, 3, 5, 5, 3, 1, 1, 1, 1, 0.5, 22, off_mag=4.0)
 
 
+def gen_point_sample():
+    """Region-encoder point sampling: the reference's own ``point_sample`` (region_encoder.py:24-47) and the masked-mean
+    pooling lines (:135-140) on seeded inputs, incl. points on / beyond the border and a region without points."""
+    glb = {"torch": torch, "F": F}
+    fn = ast_extract(f"{REF}/visionllmv2/model/region_encoder.py", ["point_sample"], glb)["point_sample"]
+    torch.manual_seed(5)
+    N, C, H, W, P = 3, 6, 7, 5, 40
+    x = torch.randn(N, C, H, W)
+    pts = torch.rand(N, P, 2) * 1.2 - 0.1
+    pts.view(-1)[0::31] = 0.0
+    pts.view(-1)[1::37] = 1.0
+    valid = torch.rand(N, P) > 0.3
+    valid[2] = False
+    sampled = fn(x, pts, align_corners=False)
+    feats = sampled.permute(0, 2, 1) * valid.unsqueeze(-1)
+    pooled = (feats.sum(1) / valid.sum(1).unsqueeze(-1)).nan_to_num()
+    np.savez_compressed(os.path.join(OUT, "point_sample.npz"), input=x.numpy(), coords=pts.numpy(), valid=valid.numpy(),
+                        sampled=sampled.numpy(), pooled=pooled.numpy(), torch_version=np.array(torch.__version__))
+    print("point_sample:", tuple(sampled.shape), pooled[0, :3].tolist())
+
+
 # --------------------------------------------------------------------------------------------------
 def load_intern_vit():
     import transformers.activations, transformers.modeling_outputs, transformers.modeling_utils  # noqa: F401 (before the stub)
@@ -281,6 +302,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_msda()
     gen_dcnv3()
+    gen_point_sample()
     gen_intern_vit()
     gen_clip()
     gen_bridge()
