@@ -99,6 +99,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
     const int nkt = (a.S + KVBLK - 1) / KVBLK;
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
 
+    // Loop-invariant LDS offsets.  swz_k / swz_v only look at key bits that come from the lane (the block constants
+    // 32*kb, 16*u, +8 do not reach them), so every fragment address is (tile base) + (one of these) + (an immediate):
+    // left to the compiler the XOR swizzle was re-evaluated per read, ~45 v_add per KV tile on a VALU-bound kernel.
+    int kofs[KS], vofs[DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kofs[ks] = l31 * (D * 2) + (((2 * ks + hh) ^ swz_k<D>(l31)) << 4);
+    {
+        const int krow = 4 * hh + ((lane & 15) >> 2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const int c = d * 4 + 2 * ((lane >> 4) & 1) + (((lane & 15) & 3) >> 1);
+            vofs[d] = krow * (D * 2) + ((c ^ swz_v<D>(krow)) << 4) + (((lane & 15) & 1) << 3);
+        }
+    }
     // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
     auto qk = [&](const char *ks_, f32x16_t (&st)[2]) {
         if (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -106,11 +120,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-            const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(
-                    ks_ + row * (D * 2) + (((2 * ks + hh) ^ swz_k<D>(row)) << 4));
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(ks_ + kofs[ks] + kb * 32 * (D * 2));
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
             }
         }
@@ -188,22 +200,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4 pw = {pk[kb][4 * u], pk[kb][4 * u + 1], pk[kb][4 * u + 2], pk[kb][4 * u + 3]};
                 const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-                const int key1 = kb * 32 + 16 * u + 4 * hh + (i16 >> 2);
-                const int key2 = key1 + 8;
+                // lane (key 4hh + i16/4 (+8 for v_hi), chunk 4d + 2g1 + (i16&3)/2) of block (kb, u): vofs[d] + immediates
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
-                    const int c = d * 4 + 2 * g1 + ((i16 & 3) >> 1);
-                    const int sub = (i16 & 1) << 3;
                     const int hidx = ((kb * 2 + u) * DB + d) * 2;   // position in the hoisted set (if it is in it)
                     s16x4_t v_lo, v_hi;
                     if (ASMTR && hidx + 1 < NHOIST) {
                         v_lo = hv[hidx < NHOIST ? hidx : 0];
                         v_hi = hv[hidx + 1 < NHOIST ? hidx + 1 : 0];
                     } else {
+                        const int blk = (kb * 32 + 16 * u) * (D * 2);   // immediate; key2 = key1 + 8 shares the swizzle
                         v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + key1 * (D * 2) + ((c ^ swz_v<D>(key1)) << 4) + sub));
+                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + vofs[d] + blk));
                         v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + key2 * (D * 2) + ((c ^ swz_v<D>(key2)) << 4) + sub));
+                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + vofs[d] + blk + 8 * (D * 2)));
                     }
                     const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
