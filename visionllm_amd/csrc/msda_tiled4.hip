@@ -336,10 +336,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void msda_fwd_tiled4_kernel(
                 int gy = y0 + wy, gx = x0 + wx;
                 const int xend = x0 + ww;
                 const char *vlb = reinterpret_cast<const char *>(vl);
-                if (y0 >= 0 && x0 >= 0 && y0 + wh < H && xend <= W) {
+                if (y0 >= 0 && x0 >= 0 && y0 + wh + 6 / ww < H && xend <= W) {
                     // interior window: the source pointer advances by one of two constant steps.  The lanes behind the
-                    // window's last pixel (tail of the last instruction; their copies land in the slack) read from map
-                    // row y0 + wh, which exists: windows that touch the last row take the general loop.
+                    // window's last pixel (tail of the last instruction, up to 7 pixels = 6 / ww extra rows of a narrow
+                    // window; their copies land in the slack) still read inside the map: windows that come closer to the
+                    // last row than that take the general loop.
                     const unsigned stepA = (unsigned)(dq * W + dr) * MD * 4, stepB = stepA + (unsigned)(W - ww) * MD * 4;
                     const char *g = vlb + (size_t)((unsigned)(gy * W + gx) * MD) * 4;
                     for (int i0 = wave_s * 8; i0 < npix; i0 += T4_QPP) {
