@@ -10,6 +10,7 @@ def main(d, out, title):
     f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     if not f:
         raise SystemExit("no *_kernel_stats.csv under " + d)
+    f.sort(key=os.path.getmtime, reverse=True)   # newest run if the directory holds several
     rows = list(csv.DictReader(open(f[0])))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(out, "w") as o:
