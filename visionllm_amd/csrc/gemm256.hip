@@ -252,21 +252,21 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     }
     a.nt = ceil_div(a.N, G2_BN);
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
-    auto cost = [&](int mt_rows) {
-        const long tiles = (long)ceil_div(a.M, 64 * mt_rows) * a.nt;
-        // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
+    // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
+    auto rounds_cost = [&](long rows, int mt_rows) {
+        const long tiles = (long)ceil_div(rows, 64 * mt_rows) * a.nt;
         return ((tiles + cus - 1) / cus) * (long)(mt_rows == 4 ? 100 : 87);
     };
-    int MT = cost(3) < cost(4) ? 3 : 4;
+    int MT = rounds_cost(a.M, 3) < rounds_cost(a.M, 4) ? 3 : 4;
     if (a.variant256 == 3 || a.variant256 == 4) MT = a.variant256;
     a.mt = ceil_div(a.M, 64 * MT);
     long tiles;
     if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
     else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;
-    // automatic: the LDS-transposed epilogue pays when a launch is only a few rounds of tiles (every CU stores at the
-    // same time: proj -11 %, 4096^3 -3 %); with many rounds the blocks drift apart and the direct stores of one hide
-    // behind the main loops of the others (fc1: +1.5 % through LDS)
-    if (a.direct_store == 2) a.direct_store = tiles > 3L * cus ? 1 : 0;
+    // automatic = through LDS: interleaved, order-robust timing (tools/gemm_ab.py) has it at -13 % on qkv (5 rounds of
+    // tiles), level on fc1 / fc2 / proj; splitting the rows into whole rounds + a tail launch was measured too and does
+    // not add to it
+    if (a.direct_store == 2) a.direct_store = 0;
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
     const size_t lds = 256 * 528;      // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB)
     static bool attr_set = false;
