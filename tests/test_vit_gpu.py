@@ -177,7 +177,7 @@ def _attn_ref(qkv, H, D, scale):
 
 
 @pytest.mark.parametrize("D", [64, 128])
-@pytest.mark.parametrize("S", [1, 5, 63, 64, 65, 128, 129, 577, 1025])
+@pytest.mark.parametrize("S", [1, 5, 32, 33, 63, 64, 65, 96, 97, 128, 129, 577, 1025])
 def test_attention_vs_oracle(D, S):
     torch.manual_seed(S * 3 + D)
     B, H = 2, 3

@@ -17,6 +17,7 @@
 //     the device by tools/probes/probe.hip);
 //   * online softmax in the exp2 domain (scale*log2(e) folded into one FMA), key tail masked in the last tile;
 //   * (tile, head) -> XCD mapping keeps all query blocks of a head on one XCD (K/V re-reads hit that L2).
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -32,6 +33,19 @@ constexpr int KVBLK = 64;   // keys per tile
 
 template <int D> __device__ __forceinline__ int swz_k(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
 template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
+
+// Combine the two key halves of a query (lanes l and l^32) with ONE v_permlane32_swap instead of a ds_bpermute round
+// trip: swapping x with itself leaves {x_lo, x_lo} in one register and {x_hi, x_hi} in the other.
+__device__ __forceinline__ float halves_max(float x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int D, bool ISV>
 __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
@@ -114,10 +128,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         }
     }
     // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
-    auto qk = [&](const char *ks_, f32x16_t (&st)[2]) {
+    // NKB = 1: the last tile holds <= 32 live keys (S = 577 / 1025: the single CLS-offset key) -- second key block skipped
+    auto qk = [&](const char *ks_, f32x16_t (&st)[2], auto nkb_) {
+        constexpr int NKB = decltype(nkb_)::value;
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
@@ -132,7 +148,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
     // online softmax of one score tile (raw scores; scale*log2e folded into the exp2 argument) + O^T += V^T P^T.
     // Lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31.  Rescale of O / l is DEFERRED while the running
     // max grows by less than THR (exp2 domain): P is then bounded by 2^THR instead of 1 (fp32 accumulation).
-    auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0) {
+    auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0, auto nkb_) {
+        constexpr int NKB = decltype(nkb_)::value;
         constexpr float THR = DEFER ? 6.0f : 0.0f;
         constexpr int NHOIST = ASMTR ? 16 : 1;          // tr-reads hoisted above the softmax: steps (kb,u) x d blocks
         s16x4_t hv[NHOIST];                              // D=64: all 16 reads of the tile; D=128: the kb=0 half
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         float mx = -1.0e30f;
         if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -161,10 +178,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 }
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * c2;          // c2 > 0: max commutes with the scaling
+        mx = halves_max(mx) * c2;                        // c2 > 0: max commutes with the scaling
         if (!DEFER || !__all(mx - m_run <= THR)) {          // wave-uniform; both halves of a query agree on mx
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         float psum = 0.f;
         uint32_t pk[2][8];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -m_run));
@@ -189,12 +206,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         l_run += psum;
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
         if constexpr (ASMTR) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the hoisted reads have landed (cdna guide 5.7, form iii)
+            // the hoisted reads have landed (cdna guide 5.7, form iii).  The registers are in/out operands of the wait so
+            // that no compiler-made copy of them (tuple assembly for the MFMA operand) can be placed above it.
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
+                           "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]),
+                           "+v"(hv[15])
+                         :
+                         : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -222,6 +246,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
+    constexpr std::integral_constant<int, 2> FULL{};
+    constexpr std::integral_constant<int, 1> HALF{};
     if constexpr (PIPE) {
         // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1].  K runs ONE tile ahead of V: iteration t computes the scores of
         // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16_t sA[2], sB[2];
-        qk(kslot(0), sA);
+        qk(kslot(0), sA, FULL);
 
         auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
             // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
@@ -242,15 +268,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
             __syncthreads();
             if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane);
             if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane);
-            if (t + 1 < nkt) qk(kslot(t + 1), nxt);
-            softmax_pv(cur, vslot(t), t * KVBLK);
+            if (t + 1 < nkt) qk(kslot(t + 1), nxt, FULL);
+            softmax_pv(cur, vslot(t), t * KVBLK, FULL);
         };
         for (int t = 0; t < nkt; t += 2) {
             iteration(t, sA, sB);
             if (t + 1 < nkt) iteration(t + 1, sB, sA);
         }
     } else {
-        // plain schedule: K_t and V_t staged together one tile ahead; QK -> softmax -> PV in sequence
+        // plain schedule: K_t and V_t staged together one tile ahead; QK -> softmax -> PV in sequence.  Waves whose 32
+        // query rows are all padding (S = 577: wave 3 of the last query block) only stage and synchronise.
+        const bool live_wave = a.no_trim || qt * QBLK + wave * 32 < a.S;
+        const bool short_tail = !a.no_trim && a.S - (nkt - 1) * KVBLK <= 32;
         stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane);
         stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane);
         for (int t = 0; t < nkt; ++t) {
@@ -262,14 +291,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
                 stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane);
                 stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane);
             }
+            if (!live_wave) continue;
             f32x16_t st[2];
-            qk(ks_, st);
-            softmax_pv(st, ks_ + TILE, t * KVBLK);
+            if (t + 1 == nkt && short_tail) {
+                qk(ks_, st, HALF);
+                softmax_pv(st, ks_ + TILE, t * KVBLK, HALF);
+            } else {
+                qk(ks_, st, FULL);
+                softmax_pv(st, ks_ + TILE, t * KVBLK, FULL);
+            }
         }
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = halves_sum(l_run);
     const float inv = 1.0f / l_tot;
     if (q_row < a.S) {
         uint16_t *orow = a.out + (((long)b * a.S + q_row) * a.H + head) * D;
@@ -299,7 +334,11 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    const int var = attn_variant() & 15;
+    // automatic: the plain schedule wins at d = 64 (114 VGPRs, 4 waves per SIMD), the K-pipelined one at d = 128
+    int var = attn_variant();
+    if (var & 32) var = D == 128 ? 3 : 2;
+    a.no_trim = (var >> 4) & 1;
+    var &= 15;
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
 #define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 2: LA(DD, 2); break; case 6: LA(DD, 6); break; \
     case 8: LA(DD, 8); break; case 10: LA(DD, 10); break; case 14: LA(DD, 14); break; case 3: LA(DD, 3); break; \

@@ -32,7 +32,8 @@ struct GemmArgs {
 
 int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
-int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio
+int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio,
+                               // bit3 asm tr-reads, bit4 no padding trim, 32 = automatic (default)
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);
@@ -58,6 +59,7 @@ struct AttnArgs {
     int q_hs, k_hs, v_hs;       // head strides
     int B, S, H;
     int nqt;                    // query tiles per (b, h) (filled by the launcher)
+    int no_trim;                // 1: process padding keys / padding query waves like live ones (A/B switch; launcher)
     float scale_log2e;
 };
 int attn_fwd_launch(AttnArgs a, int D, hipStream_t st);
