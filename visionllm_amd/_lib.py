@@ -18,7 +18,8 @@ _CTYPES = {
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "_build", "libvllm_hip.so")
+    """In-tree build; VLLM_HIP_LIB names another build of the same ABI (A/B timing of two builds in one session)."""
+    return os.environ.get("VLLM_HIP_LIB") or os.path.join(_HERE, "_build", "libvllm_hip.so")
 
 
 def build(force: bool = False, jobs: int = 8) -> str:

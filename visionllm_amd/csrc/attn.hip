@@ -47,25 +47,53 @@ __device__ __forceinline__ float halves_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// K/V staging.  The per-lane part of every source address (row-in-tile * token stride + swizzled 16-byte chunk) does not
+// change from tile to tile: it is computed ONCE (kv_lane_offsets) and each tile's LDS-DMA is then
+// (uniform tile base in SGPRs) + (that 32-bit lane offset) -> the saddr form of global_load_lds with a uniform LDS
+// destination.  Left per tile, the 64-bit row multiply / clamp / readfirstlane chain was ~12 VALU per tile on a kernel
+// whose VALU issue is the bound.  Only the last tile of a ragged S clamps rows (keys >= S re-read key S-1; masked later).
+template <int D> struct KvStage {
+    static constexpr int CPR = D / 8;           // 16-byte chunks per row
+    static constexpr int RPI = 64 / CPR;        // rows per wave instruction (1 KiB)
+    static constexpr int NI = KVBLK / RPI / 4;  // instructions per wave
+};
+
+template <int D, bool ISV>
+__device__ __forceinline__ void kv_lane_offsets(int ts, int wave, int lane, uint32_t (&vo)[KvStage<D>::NI])
+{
+    typedef KvStage<D> G;
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s) {
+        const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
+        const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));
+        vo[s] = (uint32_t)(r * ts + c * 8) * 2u;
+    }
+}
+
 template <int D, bool ISV>
 __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
-                                         int wave, int lane)
+                                         int wave, int lane, const uint32_t (&vo)[KvStage<D>::NI])
 {
-    constexpr int CPR = D / 8;           // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;        // rows per wave instruction (1 KiB)
-    constexpr int NI = KVBLK / RPI / 4;  // instructions per wave
+    typedef KvStage<D> G;
+    uint32_t off[G::NI];
 #pragma unroll
-    for (int s = 0; s < NI; ++s) {
-        const int ii = wave * NI + s;
-        const int r = ii * RPI + lane / CPR;
-        const int p = lane % CPR;
-        const int c = p ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));
-        int grow = k0 + r;
-        grow = grow < S ? grow : S - 1;
-        const uint16_t *g = base + (long)grow * ts + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(lds_tile + ii * 1024), 16, 0, 0);
+    for (int s = 0; s < G::NI; ++s) off[s] = vo[s];
+    if (k0 + KVBLK > S) {   // block-uniform: ragged last tile, rows past the last key re-read key S-1
+#pragma unroll
+        for (int s = 0; s < G::NI; ++s) {
+            const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
+            const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));   // the LDS image keeps row r's swizzle
+            const int rr = k0 + r < S ? r : S - 1 - k0;
+            off[s] = (uint32_t)(rr * ts + c * 8) * 2u;
+        }
     }
+    // ONE load site per instruction: (uniform tile base) + (32-bit lane offset) selects the saddr form, uniform LDS address
+    const char *tile = reinterpret_cast<const char *>(base + (long)k0 * ts);
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + off[s]),
+                                         (__attribute__((address_space(3))) void *)(lds_tile + (wave * G::NI + s) * 1024), 16,
+                                         0, 0);
 }
 
 // VAR bit0: software-pipelined K (scores of tile t+1 next to the softmax of tile t); bit1: deferred rescale;
@@ -73,7 +101,7 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
 // compiler treats the tr-read builtin as 'may alias the LDS-DMA in flight' and puts s_waitcnt vmcnt(0) in front of it,
 // which drains the next tile's prefetch in the middle of every iteration).
 template <int D, int VAR>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs a)
+__global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void attn_fwd_kernel(const AttnArgs a)
 {
     constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0, ASMTR = (VAR & 8) != 0;
     constexpr int KS = D / 16;            // k-steps of the QK^T product
@@ -81,7 +109,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K | V]
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR
     const int l31 = lane & 31, hh = lane >> 5;
 
     // ---- block -> (b, head, q tile): all q tiles of a (b, head) on one XCD ----
@@ -94,6 +122,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
     const uint16_t *qb = a.q + (long)b * a.q_bs + (long)head * a.q_hs;
     const uint16_t *kb_ = a.k + (long)b * a.k_bs + (long)head * a.k_hs;
     const uint16_t *vb_ = a.v + (long)b * a.v_bs + (long)head * a.v_hs;
+
+    uint32_t kvo[KvStage<D>::NI], vvo[KvStage<D>::NI];
+    kv_lane_offsets<D, false>(a.k_ts, wave, lane, kvo);
+    kv_lane_offsets<D, true>(a.v_ts, wave, lane, vvo);
 
     // ---- Q fragments (B operand): lane (q = l31, hh) holds Q[q][16*ks + 8*hh .. +7] ----
     const int q_row = qt * QBLK + wave * 32 + l31;
@@ -253,9 +285,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
         auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
         auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
-        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane);
-        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane);
-        if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane);
+        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane, kvo);
+        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane, vvo);
+        if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane, kvo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16_t sA[2], sB[2];
@@ -266,8 +298,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
             // slots of K_t / V_{t-1} that are refilled below (t = 0: the prologue's K_0 reads)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane);
-            if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane);
+            if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane, kvo);
+            if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane, vvo);
             if (t + 1 < nkt) qk(kslot(t + 1), nxt, FULL);
             softmax_pv(cur, vslot(t), t * KVBLK, FULL);
         };
@@ -280,27 +312,26 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnArgs
         // query rows are all padding (S = 577: wave 3 of the last query block) only stage and synchronise.
         const bool live_wave = a.no_trim || qt * QBLK + wave * 32 < a.S;
         const bool short_tail = !a.no_trim && a.S - (nkt - 1) * KVBLK <= 32;
-        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane);
-        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane);
-        for (int t = 0; t < nkt; ++t) {
+        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane, kvo);
+        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane, vvo);
+        auto tile_step = [&](int t, auto nkb_) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // tile t landed for every wave; everyone is done reading the other stage
             const char *ks_ = smem + (t & 1) * 2 * TILE;
             if (t + 1 < nkt) {
                 char *nx = smem + ((t + 1) & 1) * 2 * TILE;
-                stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane);
-                stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane);
+                stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane, kvo);
+                stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane, vvo);
             }
-            if (!live_wave) continue;
-            f32x16_t st[2];
-            if (t + 1 == nkt && short_tail) {
-                qk(ks_, st, HALF);
-                softmax_pv(st, ks_ + TILE, t * KVBLK, HALF);
-            } else {
-                qk(ks_, st, FULL);
-                softmax_pv(st, ks_ + TILE, t * KVBLK, FULL);
+            if (live_wave) {
+                f32x16_t st[2];
+                qk(ks_, st, nkb_);
+                softmax_pv(st, ks_ + TILE, t * KVBLK, nkb_);
             }
-        }
+        };
+        // the last tile is peeled so that the steady-state loop holds ONE copy of the body (register pressure)
+        for (int t = 0; t + 1 < nkt; ++t) tile_step(t, FULL);
+        if (short_tail) tile_step(nkt - 1, HALF); else tile_step(nkt - 1, FULL);
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
@@ -334,9 +365,9 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    // automatic: the plain schedule wins at d = 64 (114 VGPRs, 4 waves per SIMD), the K-pipelined one at d = 128
+    // automatic: the plain schedule with deferred rescale wins for both head sizes (d = 64: 128 VGPRs, 4 waves per SIMD)
     int var = attn_variant();
-    if (var & 32) var = D == 128 ? 3 : 2;
+    if (var & 32) var = 2;
     a.no_trim = (var >> 4) & 1;
     var &= 15;
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
