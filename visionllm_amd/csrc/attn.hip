@@ -70,7 +70,7 @@ __device__ __forceinline__ void kv_lane_offsets(int ts, int wave, int lane, uint
     }
 }
 
-template <int D, bool ISV>
+template <int D, bool ISV, bool RAGGED = true>
 __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
                                          int wave, int lane, const uint32_t (&vo)[KvStage<D>::NI])
 {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
     uint32_t off[G::NI];
 #pragma unroll
     for (int s = 0; s < G::NI; ++s) off[s] = vo[s];
-    if (k0 + KVBLK > S) {   // block-uniform: ragged last tile, rows past the last key re-read key S-1
+    if (RAGGED && k0 + KVBLK > S) {   // block-uniform: ragged last tile, rows past the last key re-read key S-1
 #pragma unroll
         for (int s = 0; s < G::NI; ++s) {
             const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
@@ -87,8 +87,12 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
             off[s] = (uint32_t)(rr * ts + c * 8) * 2u;
         }
     }
-    // ONE load site per instruction: (uniform tile base) + (32-bit lane offset) selects the saddr form, uniform LDS address
+    // ONE load site per instruction: (uniform tile base) + (32-bit lane offset) selects the saddr form, uniform LDS address.
+    // The empty asm keeps the zero-extension of the offset from being hoisted out of the tile loop as a 64-bit register
+    // pair (which turns every DMA back into a 64-bit VALU add + vaddr form).
     const char *tile = reinterpret_cast<const char *>(base + (long)k0 * ts);
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s) asm volatile("" : "+v"(off[s]));
 #pragma unroll
     for (int s = 0; s < G::NI; ++s)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + off[s]),
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K | V]
 
+    if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();   // fragment reads address LDS by byte offset: no static LDS here
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR
     const int l31 = lane & 31, hh = lane >> 5;
 
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     }
     // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
     // NKB = 1: the last tile holds <= 32 live keys (S = 577 / 1025: the single CLS-offset key) -- second key block skipped
-    auto qk = [&](const char *ks_, f32x16_t (&st)[2], auto nkb_) {
+    auto qk = [&](uint32_t ks_, f32x16_t (&st)[2], auto nkb_) {
         constexpr int NKB = decltype(nkb_)::value;
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(ks_ + kofs[ks] + kb * 32 * (D * 2));
+                const bf16x8_t kf = *(const __attribute__((address_space(3))) bf16x8_t *)(uintptr_t)(ks_ + kofs[ks] + kb * 32 * (D * 2));
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
             }
         }
@@ -180,13 +185,14 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     // online softmax of one score tile (raw scores; scale*log2e folded into the exp2 argument) + O^T += V^T P^T.
     // Lane holds keys kb*32 + (r&3) + 8*(r>>2) + 4*hh of query l31.  Rescale of O / l is DEFERRED while the running
     // max grows by less than THR (exp2 domain): P is then bounded by 2^THR instead of 1 (fp32 accumulation).
-    auto softmax_pv = [&](f32x16_t (&st)[2], const char *vs_, int k0, auto nkb_) {
+    auto softmax_pv = [&](f32x16_t (&st)[2], uint32_t vs_, int k0, auto nkb_, auto mask_) {
+        constexpr bool MASK = decltype(mask_)::value;   // false: the tile is known to be full (steady-state steps)
         constexpr int NKB = decltype(nkb_)::value;
         constexpr float THR = DEFER ? 6.0f : 0.0f;
         constexpr int NHOIST = ASMTR ? 16 : 1;          // tr-reads hoisted above the softmax: steps (kb,u) x d blocks
         s16x4_t hv[NHOIST];                              // D=64: all 16 reads of the tile; D=128: the kb=0 half
         if constexpr (ASMTR) {
-            const uint32_t vbase = (uint32_t)(uintptr_t)vs_;
+            const uint32_t vbase = vs_;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 // i -> (step, d, lo/hi) in the order the PV loop consumes them
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             }
         }
         float mx = -1.0e30f;
-        if (k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
+        if (MASK && k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -224,7 +230,11 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
-        float psum = 0.f;
+        // Row sums are taken from the bf16-ROUNDED probabilities (the ones the PV product uses) with one v_dot2c_f32_bf16
+        // against (1, 1) per pair: 16 VALU per tile instead of 31 adds, and O / l normalises exactly what was accumulated.
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+        float psum[2] = {0.f, 0.f};
         uint32_t pk[2][8];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -232,10 +242,11 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             for (int r = 0; r < 16; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -m_run));
                 const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c2, -m_run));
-                psum += p0 + p1;
-                pk[kb][r >> 1] = pack_bf16x2(p0, p1);
+                const uint32_t w = pack_bf16x2(p0, p1);
+                pk[kb][r >> 1] = w;
+                psum[(r >> 1) & 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), ones, psum[(r >> 1) & 1], false);
             }
-        l_run += psum;
+        l_run += psum[0] + psum[1];
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
         if constexpr (ASMTR) {
             // the hoisted reads have landed (cdna guide 5.7, form iii).  The registers are in/out operands of the wait so
@@ -267,9 +278,9 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
                     } else {
                         const int blk = (kb * 32 + 16 * u) * (D * 2);   // immediate; key2 = key1 + 8 shares the swizzle
                         v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + vofs[d] + blk));
+                            (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk));
                         v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(vs_ + vofs[d] + blk + 8 * (D * 2)));
+                            (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk + 8 * (D * 2)));
                     }
                     const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
+    constexpr std::integral_constant<bool, true> CTRUE{};
     constexpr std::integral_constant<int, 2> FULL{};
     constexpr std::integral_constant<int, 1> HALF{};
     if constexpr (PIPE) {
@@ -285,13 +297,15 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
         auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
         auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
+        auto kaddr = [&](int t) { return (uint32_t)((t & 1) * 2 * TILE); };   // LDS byte addresses (dynamic LDS starts at 0)
+        auto vaddr = [&](int t) { return (uint32_t)((t & 1) * 2 * TILE + TILE); };
         stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane, kvo);
         stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane, vvo);
         if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane, kvo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16_t sA[2], sB[2];
-        qk(kslot(0), sA, FULL);
+        qk(kaddr(0), sA, FULL);
 
         auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
             // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
@@ -300,8 +314,8 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             __syncthreads();
             if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane, kvo);
             if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane, vvo);
-            if (t + 1 < nkt) qk(kslot(t + 1), nxt, FULL);
-            softmax_pv(cur, vslot(t), t * KVBLK, FULL);
+            if (t + 1 < nkt) qk(kaddr(t + 1), nxt, FULL);
+            softmax_pv(cur, vaddr(t), t * KVBLK, FULL, CTRUE);
         };
         for (int t = 0; t < nkt; t += 2) {
             iteration(t, sA, sB);
@@ -314,24 +328,39 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         const bool short_tail = !a.no_trim && a.S - (nkt - 1) * KVBLK <= 32;
         stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane, kvo);
         stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane, vvo);
-        auto tile_step = [&](int t, auto nkb_) {
+        // One tile: wait for it, start the next one's DMA, QK -> softmax -> PV.  STAGE 0/1: the ring slot is a compile-time
+        // constant (LDS fragment addresses become register + immediate); -1: taken from t.  NEXT 0: nothing to stage,
+        // 1: the next tile is a full one (no row clamp code), 2: it may be the ragged last tile.
+        auto tile_step = [&](int t, auto nkb_, auto stage_, auto next_) {
+            constexpr int STAGE = decltype(stage_)::value, NEXT = decltype(next_)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // tile t landed for every wave; everyone is done reading the other stage
-            const char *ks_ = smem + (t & 1) * 2 * TILE;
-            if (t + 1 < nkt) {
-                char *nx = smem + ((t + 1) & 1) * 2 * TILE;
-                stage_kv<D, false>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane, kvo);
-                stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane, vvo);
+            const int slot = STAGE >= 0 ? STAGE : (t & 1);
+            const uint32_t ks_ = (uint32_t)(slot * 2 * TILE);   // LDS byte address of the K slot (dynamic LDS starts at 0)
+            if constexpr (NEXT != 0) {
+                char *nx = smem + (slot ^ 1) * 2 * TILE;
+                stage_kv<D, false, NEXT == 2>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane, kvo);
+                stage_kv<D, true, NEXT == 2>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane, vvo);
             }
             if (live_wave) {
                 f32x16_t st[2];
                 qk(ks_, st, nkb_);
-                softmax_pv(st, ks_ + TILE, t * KVBLK, nkb_);
+                softmax_pv(st, ks_ + TILE, t * KVBLK, nkb_, std::integral_constant<bool, NEXT != 1>{});
             }
         };
-        // the last tile is peeled so that the steady-state loop holds ONE copy of the body (register pressure)
-        for (int t = 0; t + 1 < nkt; ++t) tile_step(t, FULL);
-        if (short_tail) tile_step(nkt - 1, HALF); else tile_step(nkt - 1, FULL);
+        constexpr std::integral_constant<int, 0> C0{};
+        constexpr std::integral_constant<int, 1> C1{};
+        constexpr std::integral_constant<int, 2> C2{};
+        constexpr std::integral_constant<int, -1> CDYN{};
+        // steady state: steps whose next tile is full, unrolled by the ring parity; then the step that stages the (possibly
+        // ragged) last tile; then the last tile itself (peeled: one copy of the body per loop, register pressure)
+        const int n_main = nkt - 2;
+        for (int t = 0; t < n_main; t += 2) {
+            tile_step(t, FULL, C0, C1);
+            if (t + 1 < n_main) tile_step(t + 1, FULL, C1, C1);
+        }
+        if (nkt >= 2) tile_step(nkt - 2, FULL, CDYN, C2);
+        if (short_tail) tile_step(nkt - 1, HALF, CDYN, C0); else tile_step(nkt - 1, FULL, CDYN, C0);
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
