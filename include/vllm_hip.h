@@ -38,7 +38,8 @@ int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel (same results to fp32 rounding):
  * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block (default), 2 the same with 8 waves,
  * 3 LDS-tiled kernel generation 2, 4 generation 3 (software-pipelined), 5 generation 4 with the phase clock
- * (vllm_debug_counters).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel.  "gemm_direct_store": the
+ * (vllm_debug_counters).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel,
+ * 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the
  * 8-phase kernel's epilogue goes 0 through LDS (row-contiguous 16-byte stores), 1 straight from the accumulator layout,
  * 2 automatic (default; same results either way).  "attn_variant": bit0
  * software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted transpose reads, bit4 do
@@ -192,6 +193,7 @@ int vllm_point_sample_mean_f32(const float *input, const float *coords, const ui
 #define VLLM_GEMM_FORCE_256 0x200   /* 8-phase schedule, 256-row block tile */
 #define VLLM_GEMM_FORCE_192 0x300   /* 8-phase schedule, 192-row block tile */
 #define VLLM_GEMM_FORCE_4W 0x400    /* 4-wave schedule: 256x256x32 block tile, 128x128 per wave */
+#define VLLM_GEMM_FORCE_MF32 0x800  /* 8-phase schedule, 256-row block tile, v_mfma_f32_32x32x16_bf16 */
 
 /* Y[M,N] = epilogue(X[M,K] @ W[N,K]^T + bias).  Replaces F.linear / nn.Conv2d-as-GEMM on the path
  * (modeling_intern_vit.py:112,124,128,141,172-178; modeling_visionllmv2.py:162-182).

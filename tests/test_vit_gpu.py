@@ -48,7 +48,7 @@ def close(out, ref, tol=1e-2, what=""):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (577, 1024, 1024), (1000, 3200, 192), (77, 64, 640),
                                    (2 * 577, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("force", [0x100, 0x200, 0x300, 0x400])   # 128x128 2-stage, 8-phase 256-row, 8-phase 192-row, 4-wave 256x256x32
+@pytest.mark.parametrize("force", [0x100, 0x200, 0x300, 0x400, 0x800])   # 128x128 2-stage, 8-phase 256-row, 8-phase 192-row, 4-wave 256x256x32, 8-phase on 32x32x16
 def test_gemm_epilogues(M, N, K, epi, force):
     torch.manual_seed(M + N + K + epi)
     x = bf(torch.randn(M, K, device=DEV))
@@ -70,7 +70,7 @@ def test_gemm_epilogues(M, N, K, epi, force):
 
 
 @pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512), (0x300, 128), (0x300, 576), (0x400, 128), (0x400, 512),
-                                     (0x400, 576)])
+                                     (0x400, 576), (0x800, 128), (0x800, 512), (0x800, 576)])
 def test_gemm_transpose_detecting(force, M):
     """A = I-like and asymmetric B (cdna guide G9): catches swapped operands / transposed stores."""
     N = K = M
@@ -93,7 +93,7 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
     b = bf(torch.randn(N, device=DEV))
     ys = []
-    for force in (0x200, 0x200, 0x300, 0x300, 0x100, 0x400, 0x400):
+    for force in (0x200, 0x200, 0x300, 0x300, 0x100, 0x400, 0x400, 0x800, 0x800):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, force, None, None, 0, 0, stream()))
         ys.append(y)
@@ -103,6 +103,8 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     close(ys[2], ys[4], 4e-3, "192 vs 128 kernel")
     assert torch.equal(ys[5], ys[6])
     close(ys[5], ys[4], 4e-3, "4-wave vs 128 kernel")
+    assert torch.equal(ys[7], ys[8])
+    close(ys[7], ys[4], 4e-3, "8-phase 32x32x16 vs 128 kernel")
     ref = x[:257].float() @ w.float().t() + b.float()
     close(ys[0][:257], ref, 1e-2, "256 kernel vs fp32")
 

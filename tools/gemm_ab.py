@@ -26,8 +26,9 @@ def timeit(fn, iters=20):
 
 
 def main():
-    M = 23080
-    for name, N, K, epi in (("qkv", 3072, 1024, 0), ("proj", 1024, 1024, 3), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 3)):
+    shapes = [("qkv", 23080, 3072, 1024, 0), ("proj", 23080, 1024, 1024, 3), ("fc1", 23080, 4096, 1024, 2),
+              ("fc2", 23080, 1024, 4096, 3), ("sq4096", 4096, 4096, 4096, 0)]
+    for name, M, N, K, epi in shapes:
         x = torch.randn(M, K, device="cuda").bfloat16()
         w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
         b = torch.zeros(N, device="cuda").bfloat16()
@@ -42,7 +43,7 @@ def main():
             t = timeit(f)
             _lib.set_option("gemm_direct_store", 2)
             return t
-        modes = {"default": (0, 2), "256_direct": (0x200, 1), "256_lds": (0x200, 0), "192_direct": (0x300, 1), "192_lds": (0x300, 0)}
+        modes = {"default": (0, 2), "256_direct": (0x200, 1), "256_lds": (0x200, 0), "192_direct": (0x300, 1), "192_lds": (0x300, 0), "mf32_lds": (0x800, 0)}
         for _ in range(3):
             for k, (f, d) in modes.items():
                 run(f, d)   # warm-up of every code path

@@ -32,7 +32,10 @@ constexpr int OFF_A0 = 0, OFF_A1 = G2_HALF, OFF_B0 = 2 * G2_HALF, OFF_B1 = 3 * G
 // Refill one half-tile of NSEG x 8 rows (NSEG <= 16): one LDS-DMA instruction per 8 rows, EXACTLY 2 per wave (the counted
 // vmcnt waits assume that): waves whose segments do not exist (NSEG < 16) reload the last real segment into the unused
 // tail of the 16 KiB slot.
-template <int NSEG>
+// SWZ1: chunk swizzle (r >> 1) & 7 instead of r & 7.  The 32x32x16 fragments are read as (row = lane & 31, chunk pair
+// bit = lane >> 5): a ds_read_b128 lane group then holds rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of ONE chunk, and
+// rows 8 apart must land on different banks (same scheme as the attention K tile, attn.hip swz_k).
+template <int NSEG, bool SWZ1 = false>
 __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int ld, int row0, int nrows, int k0,
                                            char *lds_half, int wave, int lane, int skipP)
 {
@@ -41,7 +44,7 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
         const int seg = wave * 2 + s;
         const int sseg = seg < NSEG ? seg : NSEG - 1;      // source segment (dummy reload for idle slots)
         const int r = sseg * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (r & 7);
+        const int c = (lane & 7) ^ (SWZ1 ? ((r >> 1) & 7) : (r & 7));
         int grow = row0 + r;
         grow = grow < nrows ? grow : nrows - 1;
         if (skipP > 0) grow += grow / skipP + 1;
@@ -60,9 +63,22 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
 
 // MT = 16-row m tiles per wave per A half: 4 -> 256-row block tile, 3 -> 192 rows (better tile-count quantisation on
 // 256 CUs for some shapes: 23080 x 1024 is 364 tiles = 1.42 rounds at 256 rows but 484 = 1.89 rounds at 192).
-template <int EPI, int MT>
+// MF32 ("gemm_variant" 4 / VLLM_GEMM_FORCE_MF32; opt-in, NOT the default): the same pipeline on
+// v_mfma_f32_32x32x16_bf16 (MT = 4 only).  Measured (tools/gemm_ab.py, tools/pmc_gemm_variants.sh): 114 us at 4096^3
+// against 100 us for the 16x16x32 schedule and 89 us for hipBLASLt; 165 / 219 us on qkv / fc1 against 146 / 197.  The
+// MFMA section of a phase shrinks to 256 cycles but the phase period stays ~470: what paces it is the refill -- two
+// LDS-DMA instructions per wave per phase stall the issuing wave ~100 cycles each wherever they are placed (read section
+// or between the MFMAs), i.e. the L2 -> LDS path at 64 KiB per 2048 MFMA cycles per CU, not LDS reads (balancing the
+// fragment reads 8/4/8/8 per phase changed nothing, SQ_LDS_BANK_CONFLICT is 0.3 % of LDS cycles).  Kept as a measured
+// variant; a faster GEMM on this part needs fewer refill bytes per flop (a larger block tile), not a faster inner loop.  The 16x16x32 instruction issues every ~24 cycles
+// (2/3 of the matrix peak, tools/probes/mfma_rate.hip), the 32x32x16 one every 32 cycles for twice the flops.  A wave's
+// quadrant piece is then two 32(m) x 32(n) blocks, 8 MFMAs per phase; fragments are 16 bytes of one row per lane
+// (row = lane & 31, k half = lane >> 5), the k16 step ks selects chunk pair 2ks, 2ks+1 -> byte offset ^ (ks << 5).
+template <int EPI, int MT, bool MF32 = false>
 __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmArgs a)
 {
+    static_assert(!MF32 || MT == 4, "32x32x16 path: 256-row tiles only");
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wr = wave >> 2, wc = wave & 3;
@@ -86,58 +102,113 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     const int m0 = tm_idx * BM_, n0 = tn_idx * G2_BN;
     const int nk = a.K / G2_BK;
 
-    f32x4_t acc[4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
+    f32x4_t acc[MF32 ? 1 : 4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
+    f32x16_t acc32[MF32 ? 4 : 1][2];     // MF32: [quadrant][m block of 32]
+    if constexpr (MF32) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 16; ++r) acc32[q][j][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
 
     // per-lane LDS byte offsets inside a half-tile for the two fragment kinds (ks = 0 / 1 differ by XOR 4 chunks)
     int xoff[MT], woff[2];
+    const int l31 = lane & 31, hi = lane >> 5;
+    if constexpr (MF32) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int r = wr * (16 * MT) + t * 16 + fr;
-        xoff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
-    }
+        for (int t = 0; t < 2; ++t) {
+            const int r = wr * 64 + t * 32 + l31;
+            xoff[t] = r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+        }
+        const int r = wc * 32 + l31;
+        woff[0] = r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int r = wc * 32 + t * 16 + fr;
-        woff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
+        for (int t = 0; t < MT; ++t) {
+            const int r = wr * (16 * MT) + t * 16 + fr;
+            xoff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = wc * 32 + t * 16 + fr;
+            woff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
+        }
     }
-    bf16x8_t xf[MT][2], wf[2][2];
+    bf16x8_t xf[MT][2], wf[2][2];   // MF32: xf[2 m blocks x 2][..] viewed as [jb*2 + ks/2][ks&1], wf[ks/2][ks&1]
+    bf16x8_t xg[MF32 ? 2 : 1][2];   // MF32: third 16-register X buffer (see the MF32 loop)
 
     auto k_of = [&](int t) { return (t < nk ? t : nk - 1) * G2_BK; };   // clamped: tail refills are harmless
     auto issue_A = [&](int half, int stage, int t) {
-        issue_half<4 * MT>(a.X, a.ldx, m0 + half * (32 * MT), a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0),
+        issue_half<4 * MT, MF32>(a.X, a.ldx, m0 + half * (32 * MT), a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0),
                            wave, lane, a.xP);
     };
     auto issue_B = [&](int half, int stage, int t) {
-        issue_half<16>(a.W, a.ldw, n0 + half * 128, a.N, k_of(t), smem + stage * G2_STAGE + (half ? OFF_B1 : OFF_B0), wave,
+        issue_half<16, MF32>(a.W, a.ldw, n0 + half * 128, a.N, k_of(t), smem + stage * G2_STAGE + (half ? OFF_B1 : OFF_B0), wave,
                        lane, 0);
     };
     auto read_x = [&](const char *half) {
+        if constexpr (MF32) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            xf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + xoff[t]);
-            xf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[t] ^ 64));   // chunk index + 4  (ks = 1)
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    xf[jb * 2 + (ks >> 1)][ks & 1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[jb] ^ (ks << 5)));
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                xf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + xoff[t]);
+                xf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[t] ^ 64));   // chunk index + 4  (ks = 1)
+            }
         }
     };
     auto read_w = [&](const char *half) {
+        if constexpr (MF32) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            wf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + woff[t]);
-            wf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[t] ^ 64));
+            for (int ks = 0; ks < 4; ++ks) wf[ks >> 1][ks & 1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[0] ^ (ks << 5)));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + woff[t]);
+                wf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[t] ^ 64));
+            }
         }
     };
-#define G2_MMA(Q)                                                                                               \
+#define G2_MMA(Q, MID)                                                                                          \
     do {                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                          \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                  \
-                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], xf[j][ks], acc[Q][i][j], 0, 0, 0); \
+        if constexpr (MF32) {                                                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                  \
+                _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                \
+                    acc32[Q][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks >> 1][ks & 1], xf[jb * 2 + (ks >> 1)][ks & 1], acc32[Q][jb], 0, 0, 0); \
+                if (ks == 0) { MID; }   /* the refill's LDS-DMA goes out under the first MFMAs of the phase */      \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
+                    _Pragma("unroll") for (int j = 0; j < MT; ++j)                                              \
+                        acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], xf[j][ks], acc[Q][i][j], 0, 0, 0); \
+        }                                                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+#define G2_MMA32(Q, XB0, O0, XB1, O1, MID)                                                                      \
+    do {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
+            acc32[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks >> 1][ks & 1], XB0[O0 + (ks >> 1)][ks & 1], acc32[Q][0], 0, 0, 0); \
+            acc32[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks >> 1][ks & 1], XB1[O1 + (ks >> 1)][ks & 1], acc32[Q][1], 0, 0, 0); \
+            if (ks == 0) { MID; }                                                                               \
+        }                                                                                                       \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
@@ -149,34 +220,83 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     G2_BARRIER();
     if (wr == 1) G2_BARRIER();   // stagger: group 1 runs one barrier behind group 0
 
+    if constexpr (MF32) {
+        // 32x32x16 schedule.  A phase's MFMA section is 8 x 32 = 256 cycles, so the other group's read section has to fit
+        // in that: (a) the refill's LDS-DMA is issued INSIDE the MFMA section (after the first two MFMAs), (b) the twelve
+        // fragment reads of phase 1 are split: the first m block of A0(t+1) is read one phase early, in phase 4 of tile t
+        // (A0(t+1) is retired by a counted vmcnt(8) + the barrier of phase 3) -> reads per phase 8 / 4 / 8 / 8.
+        // X fragment buffers (16 registers each): R0 = xf[0..1], R1 = xf[2..3], R2 = xg[0..1].
+        //   A0: m block 0 in R0, m block 1 in R1 (phases 1, 2);  A1: m block 0 in R1, m block 1 in R2 (phases 3, 4).
+        auto read_blk = [&](const char *half, int jb, bf16x8_t (&dst)[2][2]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                dst[ks >> 1][ks & 1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[jb] ^ (ks << 5)));
+        };
+        bf16x8_t (&R0)[2][2] = *reinterpret_cast<bf16x8_t (*)[2][2]>(&xf[0]);
+        bf16x8_t (&R1)[2][2] = *reinterpret_cast<bf16x8_t (*)[2][2]>(&xf[2]);
+        read_blk(smem + OFF_A0, 0, R0);   // tile 0's first block (later tiles: phase 4 of the tile before)
+        for (int t = 0; t < nk; ++t) {
+            const int s = t & 1;
+            const char *st = smem + s * G2_STAGE;
+            // phase 1: quadrant (A0,B0)
+            read_blk(st + OFF_A0, 1, R1); read_w(st + OFF_B0);
+            G2_WAIT_LGKM0(); G2_BARRIER();
+            G2_MMA32(0, xf, 0, xf, 2, issue_B(0, s ^ 1, t + 1));
+            G2_BARRIER();
+            // phase 2: quadrant (A0,B1)
+            read_w(st + OFF_B1);
+            G2_WAIT_LGKM0(); G2_BARRIER();
+            G2_MMA32(1, xf, 0, xf, 2, issue_A(0, s, t + 2));
+            G2_BARRIER();
+            // phase 3: quadrant (A1,B1); retire A0(t+1) for the early read of phase 4
+            read_blk(st + OFF_A1, 0, R1); read_blk(st + OFF_A1, 1, xg);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            G2_WAIT_LGKM0(); G2_BARRIER();
+            G2_MMA32(3, xf, 2, xg, 0, issue_B(1, s, t + 2));
+            G2_BARRIER();
+            // phase 4: quadrant (A1,B0); first block of A0(t+1) (other stage) read early
+            read_w(st + OFF_B0);
+            read_blk(smem + (s ^ 1) * G2_STAGE + OFF_A0, 0, R0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            G2_WAIT_LGKM0(); G2_BARRIER();
+            G2_MMA32(2, xf, 2, xg, 0, issue_A(1, s, t + 2));
+            G2_BARRIER();
+        }
+    } else {
     for (int t = 0; t < nk; ++t) {
         const int s = t & 1;
         const char *st = smem + s * G2_STAGE;
         // phase 1: quadrant (A0,B0); refill B0 of the OTHER stage with tile t+1
         read_x(st + OFF_A0); read_w(st + OFF_B0);
-        issue_B(0, s ^ 1, t + 1);
+        if constexpr (!MF32) issue_B(0, s ^ 1, t + 1);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(0);
+        G2_MMA(0, issue_B(0, s ^ 1, t + 1));
         G2_BARRIER();
         // phase 2: quadrant (A0,B1); refill A0 (this stage) with tile t+2
         read_w(st + OFF_B1);
-        issue_A(0, s, t + 2);
+        if constexpr (!MF32) issue_A(0, s, t + 2);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(1);
+        G2_MMA(1, issue_A(0, s, t + 2));
         G2_BARRIER();
         // phase 3: quadrant (A1,B1); refill B1 with tile t+2
         read_x(st + OFF_A1);
-        issue_B(1, s, t + 2);
+        if constexpr (!MF32) issue_B(1, s, t + 2);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(3);
+        G2_MMA(3, issue_B(1, s, t + 2));
         G2_BARRIER();
-        // phase 4: quadrant (A1,B0); refill A1 with tile t+2; retire everything but the last 3 half-tiles
+        // phase 4: quadrant (A1,B0); refill A1 with tile t+2; retire everything but the last 3 half-tiles (MF32: the refill
+        // of this phase is issued after the wait, inside the MFMA section -> 2 half-tiles outstanding at the wait)
         read_w(st + OFF_B0);
-        issue_A(1, s, t + 2);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (!MF32) {
+            issue_A(1, s, t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(2);
+        G2_MMA(2, issue_A(1, s, t + 2));
         G2_BARRIER();
+    }
     }
     if (wr == 0) G2_BARRIER();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -189,6 +309,32 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     const bool via_lds = !a.direct_store && EPI != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
     if (via_lds) {
         __builtin_amdgcn_s_barrier();   // every wave is out of the main loop: no fragment read of the ring is pending
+        if constexpr (MF32) {
+            // accumulator register 4g + e of block jb: feature wc*32 + 8g + 4hi + e, token wr*64 + jb*32 + l31
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = qj * 128 + wc * 32 + g * 8 + hi * 4;
+                    const int n = n0 + nl;
+                    const bool nok = n < a.N;
+                    const EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const int ml = qi * 128 + wr * 64 + jb * 32 + l31;
+                        const int m = m0 + ml;
+                        const f32x4_t av = {acc32[q][jb][4 * g], acc32[q][jb][4 * g + 1], acc32[q][jb][4 * g + 2], acc32[q][jb][4 * g + 3]};
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (nok && m < a.M) epi_value<EPI>(a, m, n, av, cols, v);
+                        uint2_t o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2_t *>(smem + ml * OPITCH + nl * 2) = o;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int qi = q >> 1, qj = q & 1;
@@ -211,6 +357,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 }
             }
         }
+        }
         __builtin_amdgcn_s_barrier();
         const int t = threadIdx.x, c8 = (t & 31) * 8;   // 32 lanes x 16 B = one 512-byte tile row
 #pragma unroll 4
@@ -223,6 +370,25 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         }
         return;
     }
+    if constexpr (MF32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + qj * 128 + wc * 32 + g * 8 + hi * 4;
+                if (n >= a.N) continue;
+                const EpiCols cols = epi_cols<EPI>(a, n);
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int m = m0 + qi * 128 + wr * 64 + jb * 32 + l31;
+                    if (m >= a.M) continue;
+                    const f32x4_t av = {acc32[q][jb][4 * g], acc32[q][jb][4 * g + 1], acc32[q][jb][4 * g + 2], acc32[q][jb][4 * g + 3]};
+                    epi_store<EPI>(a, m, n, av, cols);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int qi = q >> 1, qj = q & 1;
@@ -238,6 +404,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 epi_store<EPI>(a, m, n, acc[q][i][j], cols);
             }
         }
+    }
     }
 }
 
@@ -259,6 +426,8 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     };
     int MT = rounds_cost(a.M, 3) < rounds_cost(a.M, 4) ? 3 : 4;
     if (a.variant256 == 3 || a.variant256 == 4) MT = a.variant256;
+    const bool mf32 = a.variant256 == 5;   // 256-row tiles on the 32x32x16 instruction
+    if (mf32) MT = 4;
     a.mt = ceil_div(a.M, 64 * MT);
     long tiles;
     if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
@@ -272,12 +441,14 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     static bool attr_set = false;
     if (!attr_set) {
 #define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-        SETATTR(EPI_BIAS); SETATTR(EPI_GELU); SETATTR(EPI_QUICK_GELU); SETATTR(EPI_RESIDUAL); SETATTR(EPI_EMBED);
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        SETATTR(EPI_BIAS); SETATTR(EPI_GELU); SETATTR(EPI_QUICK_GELU); SETATTR(EPI_RESIDUAL); SETATTR(EPI_EMBED); SETATTR(EPI_F32);
 #undef SETATTR
         attr_set = true;
     }
-#define L(E) do { if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4>), grid, block, lds, st, a); \
+#define L(E) do { if (mf32) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4, true>), grid, block, lds, st, a); \
+                  else if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4>), grid, block, lds, st, a); \
                   else VLLM_LAUNCH((gemm256_bf16_kernel<E, 3>), grid, block, lds, st, a); } while (0)
     switch (epi) {
     case EPI_BIAS: L(EPI_BIAS); break;

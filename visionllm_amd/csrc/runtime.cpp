@@ -36,7 +36,7 @@ int gemm_variant_override()
     if (g_gemm_variant < 0) {
         const char *e = getenv("VLLM_GEMM_VARIANT");
         g_gemm_variant = e ? atoi(e) : 0;
-        if (g_gemm_variant < 0 || g_gemm_variant > 3) g_gemm_variant = 0;
+        if (g_gemm_variant < 0 || g_gemm_variant > 4) g_gemm_variant = 0;
     }
     return g_gemm_variant;
 }
@@ -64,7 +64,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 63; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
-        if (value < 0 || value > 3) { vllm::set_error("gemm_variant must be 0..3"); return VLLM_EINVAL; }
+        if (value < 0 || value > 4) { vllm::set_error("gemm_variant must be 0..4"); return VLLM_EINVAL; }
         vllm::g_gemm_variant = value;
         return old;
     }
