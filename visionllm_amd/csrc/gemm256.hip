@@ -143,6 +143,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             woff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
         }
     }
+    bf16x8_t wg[2][2];              // second W fragment set: B0's fragments (wf) stay live from phase 1 to phase 4
     bf16x8_t xf[MT][2], wf[2][2];   // MF32: xf[2 m blocks x 2][..] viewed as [jb*2 + ks/2][ks&1], wf[ks/2][ks&1]
     bf16x8_t xg[MF32 ? 2 : 1][2];   // MF32: third 16-register X buffer (see the MF32 loop)
 
@@ -170,32 +171,33 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             }
         }
     };
-    auto read_w = [&](const char *half) {
+    auto read_w_into = [&](const char *half, bf16x8_t (&dst)[2][2]) {
         if constexpr (MF32) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) wf[ks >> 1][ks & 1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[0] ^ (ks << 5)));
+            for (int ks = 0; ks < 4; ++ks) dst[ks >> 1][ks & 1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[0] ^ (ks << 5)));
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                wf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + woff[t]);
-                wf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[t] ^ 64));
+                dst[t][0] = *reinterpret_cast<const bf16x8_t *>(half + woff[t]);
+                dst[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[t] ^ 64));
             }
         }
     };
-#define G2_MMA(Q, MID)                                                                                          \
+    auto read_w = [&](const char *half) { read_w_into(half, wf); };
+#define G2_MMA(Q, MID, WF)                                                                                      \
     do {                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                          \
         if constexpr (MF32) {                                                                                   \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                  \
                 _Pragma("unroll") for (int jb = 0; jb < 2; ++jb)                                                \
-                    acc32[Q][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks >> 1][ks & 1], xf[jb * 2 + (ks >> 1)][ks & 1], acc32[Q][jb], 0, 0, 0); \
+                    acc32[Q][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ks >> 1][ks & 1], xf[jb * 2 + (ks >> 1)][ks & 1], acc32[Q][jb], 0, 0, 0); \
                 if (ks == 0) { MID; }   /* the refill's LDS-DMA goes out under the first MFMAs of the phase */      \
             }                                                                                                   \
         } else {                                                                                                \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
                     _Pragma("unroll") for (int j = 0; j < MT; ++j)                                              \
-                        acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], xf[j][ks], acc[Q][i][j], 0, 0, 0); \
+                        acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][ks], xf[j][ks], acc[Q][i][j], 0, 0, 0); \
         }                                                                                                       \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -270,23 +272,22 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         read_x(st + OFF_A0); read_w(st + OFF_B0);
         if constexpr (!MF32) issue_B(0, s ^ 1, t + 1);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(0, issue_B(0, s ^ 1, t + 1));
+        G2_MMA(0, issue_B(0, s ^ 1, t + 1), wf);
         G2_BARRIER();
         // phase 2: quadrant (A0,B1); refill A0 (this stage) with tile t+2
-        read_w(st + OFF_B1);
+        read_w_into(st + OFF_B1, wg);   // B0's fragments stay in wf for phase 4 (4 fewer ds_read_b128 per K tile)
         if constexpr (!MF32) issue_A(0, s, t + 2);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(1, issue_A(0, s, t + 2));
+        G2_MMA(1, issue_A(0, s, t + 2), wg);
         G2_BARRIER();
         // phase 3: quadrant (A1,B1); refill B1 with tile t+2
         read_x(st + OFF_A1);
         if constexpr (!MF32) issue_B(1, s, t + 2);
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(3, issue_B(1, s, t + 2));
+        G2_MMA(3, issue_B(1, s, t + 2), wg);
         G2_BARRIER();
         // phase 4: quadrant (A1,B0); refill A1 with tile t+2; retire everything but the last 3 half-tiles (MF32: the refill
         // of this phase is issued after the wait, inside the MFMA section -> 2 half-tiles outstanding at the wait)
-        read_w(st + OFF_B0);
         if constexpr (!MF32) {
             issue_A(1, s, t + 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         G2_WAIT_LGKM0(); G2_BARRIER();
-        G2_MMA(2, issue_A(1, s, t + 2));
+        G2_MMA(2, issue_A(1, s, t + 2), wf);
         G2_BARRIER();
     }
     }
