@@ -231,6 +231,48 @@ def test_backward_f32_vectorised_vs_oracle(D, M, P):
     assert bad.mean() < 2e-3, bad.mean()
 
 
+@pytest.mark.parametrize("shapes,B,M", [([(72, 64), (36, 32), (18, 16), (9, 8)], 2, 8), ([(65, 67), (33, 34)], 1, 3)])
+def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M):
+    """Encoder self-attention shape (Lq = S >= 4096, D 32, P 4): the LDS-tiled backward (window accumulation + flush), its
+    out-of-window fallback (far offsets), rejected / non-finite points, and the plain atomic kernel agree with the oracle."""
+    from visionllm_amd import _lib
+    g = make_inputs(B, M, 32, shapes, 4, mode="encoder_like", seed=len(shapes) + M)
+    loc = g["loc"].copy()
+    flat = loc.reshape(-1, 2)
+    flat[7::41] += 0.37            # far offsets: some (tile, level) windows exceed the LDS budget -> global-atomic fallback
+    flat[3::29] = 1.7              # rejected points
+    flat[5::97] = np.nan
+    Lq = loc.shape[1]
+    rng = np.random.default_rng(11)
+    go = rng.standard_normal((B, Lq, M * 32)).astype(np.float32)
+    rv, rl, rw = O.backward(g["value"].astype(np.float64), g["shapes"], g["lsi"], loc.astype(np.float64),
+                            g["attw"].astype(np.float64), go.astype(np.float64))
+    sel = np.isfinite(loc).all(-1)
+    for l, (H, W) in enumerate(shapes):   # d/dloc is discontinuous at exact pixel borders (see the vectorised test)
+        fy = np.nan_to_num(loc[:, :, :, l, :, 1].astype(np.float64)) * H - 0.5
+        fx = np.nan_to_num(loc[:, :, :, l, :, 0].astype(np.float64)) * W - 0.5
+        sel[:, :, :, l] &= ~((np.abs(fy - np.round(fy)) < 1e-4) | (np.abs(fx - np.round(fx)) < 1e-4))
+    old = _lib.set_option("msda_tiled", 1)
+    try:
+        res = {}
+        for mode in (1, 0):   # 1: LDS-tiled backward, 0: plain atomic kernel
+            _lib.set_option("msda_tiled", mode)
+            gv, gl, gw = A.ms_deform_attn_backward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]),
+                                                   _t(go), 64)
+            res[mode] = (gv.cpu().numpy(), gl.cpu().numpy(), gw.cpu().numpy())
+            assert np.isfinite(res[mode][0]).all() and np.isfinite(res[mode][1]).all() and np.isfinite(res[mode][2]).all()
+            np.testing.assert_allclose(res[mode][2][sel], rw[sel], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(res[mode][1][sel], rl[sel], rtol=2e-3, atol=2e-3)
+            bad = np.abs(res[mode][0] - rv) > 1e-3 * (1 + np.abs(rv))
+            assert bad.mean() < 2e-3, (mode, bad.mean())
+        # the two kernels evaluate every point with the same instruction sequence: per-point gradients are identical,
+        # grad_value differs only by the order of the atomic sums
+        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][1], res[0][1])
+        np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4, atol=1e-4)
+    finally:
+        _lib.set_option("msda_tiled", old)
+
+
 def test_modules_match_oracle_composition():
     """MSDeformAttn / mmcv module / GDINO module == (torch Linear layers + oracle op) on the same weights."""
     torch.manual_seed(0)

@@ -68,8 +68,12 @@ def main():
     for k in ("value", "loc", "attw"):
         t[k] = t[k].repeat(a.B, *([1] * (t[k].dim() - 1))).contiguous()
     go = torch.randn(a.B, t["loc"].shape[1], 256, device=dev)
-    sec = timeit(lambda: A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64), 5)
-    print(json.dumps(dict(mode="encoder_like", dtype="f32_backward", B=a.B, Lq=int(t["loc"].shape[1]), us=sec * 1e6)))
+    from visionllm_amd import _lib
+    for name, mode in (("f32_backward_tiled", 1), ("f32_backward_plain_atomics", 0)):
+        old = _lib.set_option("msda_tiled", mode)
+        sec = timeit(lambda: A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64), 5)
+        _lib.set_option("msda_tiled", old)
+        print(json.dumps(dict(mode="encoder_like", dtype=name, B=a.B, Lq=int(t["loc"].shape[1]), us=sec * 1e6)))
     return res
 
 

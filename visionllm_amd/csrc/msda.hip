@@ -550,6 +550,13 @@ extern "C" int vllm_msda_sample_index_f32(const int64_t *shapes, const float *lo
     return VLLM_OK;
 }
 
+namespace vllm {
+bool msda_bwd_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *grad_out, const void *loc);   // msda_bwd_tiled.hip
+int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
+                          hipStream_t st);
+}  // namespace vllm
+
 template <int LPG>
 static int launch_bwd_vec(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                           const float *attw, const float *grad_out, int B, int S, int M, int L, int Lq, int P, float *gv,
@@ -577,6 +584,9 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
     VLLM_REQUIRE((long)B * Lq == 0 || (value && shapes && lsi && loc && attw && grad_out && gv && gl && gw),
                  "msda_backward_f32: null pointer");
+    // encoder self-attention shape: grad_value accumulated per (query tile, level) window in LDS (msda_bwd_tiled.hip)
+    if ((long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv))
+        return msda_bwd_tiled_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
     if ((long)B * Lq != 0 && D % 4 == 0 && (P == 1 || P == 2 || P == 4 || P == 8) && aligned16(value) &&
         aligned16(grad_out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0) {
         const int lpg = D / 4;
