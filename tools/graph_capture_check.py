@@ -1,3 +1,6 @@
+"""hipGraph capture of one bench step (ViT-L + bridge on the main stream, MSDA on the side stream) replayed against the eager
+step: measured 23.05 vs 23.02 ms -- the native runtime enqueues a step in 1.7 ms of CPU time, the GPU is never starved, so
+bench.py stays eager."""
 import os, sys, time, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import bench
