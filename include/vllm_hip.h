@@ -38,7 +38,7 @@ int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel (same results to fp32 rounding):
  * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block (default), 2 the same with 8 waves,
  * 3 LDS-tiled kernel generation 2, 4 generation 3 (software-pipelined), 5 generation 4 with the phase clock
- * (vllm_debug_counters).  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel,
+ * (vllm_debug_counters), 6 / 7 generation 5 (producer / consumer waves, two windows, one block per CU) with 4 / 8 producer waves.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel,
  * 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the
  * 8-phase kernel's epilogue goes 0 through LDS (row-contiguous 16-byte stores), 1 straight from the accumulator layout,
  * 2 automatic (default; same results either way).  "attn_variant": bit0

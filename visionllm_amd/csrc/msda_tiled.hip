@@ -327,13 +327,18 @@ static int tiled_launch_cfg(int cus, const float *value, const int64_t *shapes, 
 int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                        const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_tiled4.hip
 
+int msda_tiled5_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                       const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_tiled5.hip
+
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
     const int mode = msda_tiled_enabled();
     // generation 4 keeps pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
-    if ((mode == 1 || mode == 2 || mode == 5) && fits32)
+    if ((mode == 6 || mode == 7) && fits32 && (reinterpret_cast<uintptr_t>(loc) & 15u) == 0)
+        return msda_tiled5_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if ((mode == 1 || mode == 2 || mode == 5 || mode == 6 || mode == 7) && fits32)
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     if (mode == 4) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     static int cus = 0;
