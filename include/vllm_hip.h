@@ -43,7 +43,7 @@ int vllm_device_info(char *name, int cap);
  * 8-phase kernel's epilogue goes 0 through LDS (row-contiguous 16-byte stores), 1 straight from the accumulator layout,
  * 2 automatic (default; same results either way).  "attn_variant": bit0
  * software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted transpose reads, bit4 do
- * not trim padding keys / padding query waves, 32 automatic (default; currently 2).  Environment variables
+ * not trim padding keys / padding query waves, bit6 (head_dim 64) two 32-row query groups per wave (measured slower, opt-in), 32 automatic (default; currently 2).  Environment variables
  * VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous value or
  * VLLM_EINVAL for an unknown name. */
 int vllm_set_option(const char *name, int value);

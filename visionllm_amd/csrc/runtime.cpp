@@ -27,7 +27,7 @@ int attn_variant()
 {
     if (g_attn_variant < 0) {
         const char *e = getenv("VLLM_ATTN_VARIANT");
-        g_attn_variant = e ? (atoi(e) & 63) : 32;
+        g_attn_variant = e ? (atoi(e) & 127) : 32;
     }
     return g_attn_variant;
 }
@@ -61,7 +61,7 @@ extern "C" int vllm_set_option(const char *name, int value)
         return old;
     }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
-    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 63; return old; }
+    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 127; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
         if (value < 0 || value > 4) { vllm::set_error("gemm_variant must be 0..4"); return VLLM_EINVAL; }
