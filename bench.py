@@ -233,6 +233,8 @@ def main():
                          "image through InternViT-6B + pixel-shuffle + internvl_mlp projector)")
     ap.add_argument("--msda-stream", type=int, default=1, choices=[0, 1],
                     help="1 (default): the MSDA kernels run on a side stream next to the ViT; 0: everything on one stream")
+    ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="0 / 1 (default): one launch sequence; k: the tiles as k chunks on k streams (measured slower)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -252,6 +254,9 @@ def main():
     from visionllm_amd.dist import all_gather_visual_tokens
 
     ivit = args.workload == "internvit6b"
+    if args.encoder_chunks:
+        from visionllm_amd import vit_common
+        vit_common.set_encoder_chunks(args.encoder_chunks)
     enc, bridge = build_intern_model(dev) if ivit else build_model(dev)
     if ivit:
         enc.keep_hidden_states = (-1, -2, -3)   # 49 x 262 MB otherwise; the reference reads only these
@@ -331,7 +336,7 @@ def main():
                        "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
                        "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096", "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
                        "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else ""),
-                       "streams": "vit+projector | msda (side stream)" if args.msda_stream else "single"},
+                       "streams": ("vit+projector | msda (side stream)" if args.msda_stream else "single") + ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
             "roofline": {k: rl["gemm"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": rl["gemm"]["kernel"]},
             "rooflines": rl,
         }

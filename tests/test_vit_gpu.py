@@ -316,6 +316,33 @@ def test_clip_small_vs_reference_golden():
     close(out.hidden_states[-2], torch.from_numpy(g["hidden_states"][-2]), 3e-2, "vs HF fp32 fixture")
 
 
+@pytest.mark.parametrize("n", [5, 16, 17])
+def test_encoder_two_stream_half_batches_are_bit_identical(n):
+    """A batch run as two / three chunks on separate streams (vit_common.run_encoder, opt-in) gives exactly the hidden
+    states of the single-sequence run, for odd splits too, and repeated runs agree (no cross-stream race)."""
+    from visionllm_amd import vit_common
+    g = load_golden("internvit_small_d64.npz")
+    cfgd = _cfg(g)
+    model = InternVisionModel(InternVisionConfig(**cfgd))
+    model.load_state_dict(golden_sd(g), strict=True)
+    model = model.to(DEV).to(torch.bfloat16)
+    x0 = torch.from_numpy(g["pixel_values"])
+    torch.manual_seed(n)
+    x = bf(torch.randn(n, *x0.shape[1:])).to(DEV)
+    old = vit_common.set_encoder_chunks(1)
+    try:
+        one = model(x, output_hidden_states=True).hidden_states
+        for chunks in (2, 3):
+            vit_common.set_encoder_chunks(chunks)
+            for _ in range(2):
+                two = model(x, output_hidden_states=True).hidden_states
+                for a, b in zip(one, two):
+                    assert torch.equal(a, b), f"chunks={chunks}"
+    finally:
+        vit_common.set_encoder_chunks(old)
+    assert vit_common.encoder_chunks(40) == 1   # default: one sequence
+
+
 def test_unsupported_head_dim_fails_loudly():
     g = load_golden("internvit_tiny_qknorm.npz")  # head_dim 32
     model = InternVisionModel(InternVisionConfig(**_cfg(g)))

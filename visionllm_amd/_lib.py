@@ -149,10 +149,11 @@ BRIDGE_LINEAR, BRIDGE_MLP_GELU, BRIDGE_INTERNVL_MLP = 0, 1, 2
 _workspaces = {}
 
 
-def workspace(device, nbytes):
-    """Grow-only per-device scratch buffer (torch owns the memory; the library never allocates)."""
+def workspace(device, nbytes, slot=0):
+    """Grow-only per-device scratch buffer (torch owns the memory; the library never allocates).  ``slot`` names
+    independent buffers for work that runs concurrently on different streams."""
     import torch
-    key = (str(device),)
+    key = (str(device), slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)

@@ -68,15 +68,62 @@ def run_encoder(desc, pixel_values, num_layers, hidden_size, keep=None):
         want = {(i + L + 1) % (L + 1) for i in keep} | {L}
     states = [torch.empty((n, S, hidden_size), dtype=torch.bfloat16, device=dev) if i in want else None
               for i in range(L + 1)]
-    ptrs = (ctypes.c_void_p * (L + 1))(*[s.data_ptr() if s is not None else None for s in states])
+    # Tiles never interact inside the encoder, so a batch CAN be run as independent chunks on separate streams (opt-in:
+    # set_encoder_chunks / VLLM_ENCODER_CHUNKS), the idea being that kernels of the other chunk fill the CUs a GEMM / attention
+    # launch leaves idle in its last round of tiles.  Same kernels, same per-tile arithmetic: results are bit-identical
+    # (tested).  Measured on the bench workload (40 tiles ViT-L): 24.08 ms per step with two half-batches against 22.65 ms
+    # with one sequence -- the half-size GEMMs quantise worse than the overlap recovers -- so the default is ONE chunk.
+    chunks = encoder_chunks(n)
+    bounds = [n * c // chunks for c in range(chunks + 1)]
+    row_bytes = S * hidden_size * 2
+    px_bytes = 3 * desc.image * desc.image * pixel_values.element_size()
     with torch.cuda.device(dev):
-        ws_bytes = lib.vllm_vit_workspace_bytes(ctypes.byref(desc), n)
-        if ws_bytes < 0:
-            raise RuntimeError("vllm_vit_workspace_bytes: " + lib.vllm_last_error().decode())
-        ws = _lib.workspace(dev, ws_bytes)
-        _lib.check(lib.vllm_vit_forward(ctypes.byref(desc), _lib.ptr(pixel_values), n, ptrs, _lib.ptr(ws), ws_bytes,
-                                        _lib.current_stream(dev)), "vllm_vit_forward")
+        main = torch.cuda.current_stream(dev)
+        for c in range(chunks):
+            lo, nc = bounds[c], bounds[c + 1] - bounds[c]
+            if nc == 0:
+                continue
+            ptrs = (ctypes.c_void_p * (L + 1))(*[s.data_ptr() + lo * row_bytes if s is not None else None for s in states])
+            ws_bytes = lib.vllm_vit_workspace_bytes(ctypes.byref(desc), nc)
+            if ws_bytes < 0:
+                raise RuntimeError("vllm_vit_workspace_bytes: " + lib.vllm_last_error().decode())
+            ws = _lib.workspace(dev, ws_bytes, slot=c)
+            stream = main if c == 0 else _side_stream(dev, c)
+            if c > 0:
+                stream.wait_stream(main)   # inputs (and the workspace's previous users) are ordered on the caller's stream
+            with torch.cuda.stream(stream):
+                _lib.check(lib.vllm_vit_forward(ctypes.byref(desc), ctypes.c_void_p(pixel_values.data_ptr() + lo * px_bytes), nc,
+                                                ptrs, _lib.ptr(ws), ws_bytes, _lib.current_stream(dev)), "vllm_vit_forward")
+        for c in range(1, chunks):
+            main.wait_stream(_side_stream(dev, c))
     return states
+
+
+_ENCODER_CHUNKS = {"value": None}
+_SIDE_STREAMS = {}
+
+
+def set_encoder_chunks(k):
+    """1 (default, also None): one launch sequence per batch; k: k chunks of tiles on k streams (measured slower)."""
+    old = _ENCODER_CHUNKS["value"]
+    _ENCODER_CHUNKS["value"] = k
+    return old
+
+
+def encoder_chunks(n):
+    import os
+    k = _ENCODER_CHUNKS["value"]
+    if k is None:
+        env = os.environ.get("VLLM_ENCODER_CHUNKS")
+        k = int(env) if env else 1
+    return max(1, min(int(k), n, 4))
+
+
+def _side_stream(dev, c):
+    key = (str(dev), c)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 class LazyHiddenStates(tuple):
