@@ -126,7 +126,7 @@ def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     ab = msda_bytes(t)
-    out["msda"] = dict(kernel="msda_fwd_tiled4_kernel<4 waves> (fp32, D32, encoder shape Lq=S=37485, B=8)", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
+    out["msda"] = dict(kernel="msda_fwd_tiled4_kernel<4 waves, 3 blocks per CU> (fp32, D32, encoder shape Lq=S=37485, B=8)", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
                        unit="GB/s", frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6,
                        algorithmic_bytes=ab)
     # (2) attention kernel: MFMA bound, flops = 4*H*S^2*d per tile

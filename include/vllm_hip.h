@@ -36,7 +36,8 @@ const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel (same results to fp32 rounding):
- * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block (default), 2 the same with 8 waves,
+ * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block, 360-pixel windows, 3 blocks per CU (default),
+ * 8 the same with 560-pixel windows and 2 blocks per CU, 2 with 8 waves per block,
  * 3 LDS-tiled kernel generation 2, 4 generation 3 (software-pipelined), 5 generation 4 with the phase clock
  * (vllm_debug_counters), 6 / 7 generation 5 (producer / consumer waves, two windows, one block per CU) with 4 / 8 producer waves.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel,
  * 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the

@@ -114,7 +114,7 @@ def test_tiled_kernel_matches_gather_kernel(mode):
     try:
         plain = _run(g)
         ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-        for variant in (1, 2, 3, 4, 5, 6, 7):  # generation 4 (4 / 8 waves), 2, 3, 4 + phase clock, generation 5 (4 / 8 producer waves)
+        for variant in (1, 2, 3, 4, 5, 6, 7, 8):  # generation 4 (4 / 8 waves), 2, 3, 4 + phase clock, generation 5 (4 / 8 producer waves)
             _lib.set_option("msda_tiled", variant)
             tiled = _run(g)
             again = _run(g)
@@ -148,7 +148,7 @@ def test_nan_and_inf_sampling_locations_contribute_nothing():
     flat[12::59] = -np.inf
     ref = O.forward(g["value"], g["shapes"], g["lsi"], loc, g["attw"])
     assert np.isfinite(ref).all()
-    for tiled in (0, 1, 2, 3, 4, 6, 7):
+    for tiled in (0, 1, 2, 3, 4, 6, 7, 8):
         old = _lib.set_option("msda_tiled", tiled)
         try:
             out = A.ms_deform_attn_forward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]), 64)

@@ -13,7 +13,7 @@ def timeit(iters=10):
         A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-modes = {"gen4_4waves": 1, "gen4_8waves": 2, "gen5_4prod": 6, "gen5_8prod": 7, "gen2": 3, "gather": 0}
+modes = {"gen4_win360_3blocks": 1, "gen4_win560_2blocks": 8, "gen4_8waves": 2, "gen5_4prod": 6, "gen2": 3, "gather": 0}
 for _ in range(2):
     for k, v in modes.items():
         _lib.set_option("msda_tiled", v); timeit(3)

@@ -24,7 +24,7 @@ namespace {
 constexpr int BT_THREADS = 256;
 constexpr int BT_QPP = BT_THREADS / 8;   // 32 queries per pass (8 lanes x 4 channels = D 32)
 constexpr int BT_MAXL = 8;
-constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP, BT_WIN = 560;
+constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP, BT_WIN = 360;   // 360-pixel windows: 3 blocks per CU (see msda_tiled4_launch)
 constexpr size_t BT_LDS_WIN = (size_t)BT_WIN * 128, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
 constexpr size_t BT_LDS = BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
 
@@ -34,7 +34,7 @@ template <int K> __device__ __forceinline__ float qbc(float x)   // value of lan
 }
 template <int K> __device__ __forceinline__ int qbc(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_tiled_kernel(
+__global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out, int B, int S, int M,
     int L, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attw)
@@ -281,7 +281,7 @@ int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64
                                   (int)BT_LDS);
         attr_set = true;
     }
-    const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
+    const int grid = (cus / 8) * 8 * 3;   // persistent: 3 blocks per CU
     VLLM_LAUNCH(msda_bwd_tiled_kernel, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
                 Lq, gv, gl, gw);
     VLLM_CHECK_LAUNCH("msda_bwd_tiled_kernel");

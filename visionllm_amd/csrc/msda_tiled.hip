@@ -338,7 +338,7 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
     if ((mode == 6 || mode == 7) && fits32 && (reinterpret_cast<uintptr_t>(loc) & 15u) == 0)
         return msda_tiled5_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    if ((mode == 1 || mode == 2 || mode == 5 || mode == 6 || mode == 7) && fits32)
+    if ((mode == 1 || mode == 2 || mode == 5 || mode == 6 || mode == 7 || mode == 8) && fits32)
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     if (mode == 4) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
     static int cus = 0;

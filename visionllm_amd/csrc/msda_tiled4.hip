@@ -1,4 +1,5 @@
-// Multi-scale deformable attention forward, LDS-tiled kernel, generation 4 ("msda_tiled" options 1 (default, 4 waves per block), 2 (8 waves), 5 (phase clock)).
+// Multi-scale deformable attention forward, LDS-tiled kernel, generation 4 ("msda_tiled" options 1 (default: 4 waves per
+// block, 360-pixel windows, 3 blocks per CU), 8 (560-pixel windows, 2 blocks per CU), 2 (8 waves), 5 (phase clock)).
 //
 // Same tiling as msda_tiled.hip (one 8x16 query tile of one level x one head per work item, persistent blocks,
 // per-level exact bounding window staged into LDS with LDS-DMA), re-organised around the instruction count, which the
@@ -36,10 +37,11 @@ struct T4Shape {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 };
 constexpr int T4_ZPX = 48;                 // zero strip ahead of the window [pixels]; the pitch must stay <= ZPX - 2
-constexpr int T4_WIN = 560;                // window budget [pixels]
+constexpr int T4_WIN = 560;                // window budget [pixels] of the 2-blocks-per-CU configuration
+constexpr int T4_WIN3 = 360;               // ... of the 3-blocks-per-CU configuration (see msda_tiled4_launch)
 constexpr int T4_SLACK = 8;                // the last LDS-DMA instruction of a window may write up to 7 pixels past it
 constexpr int T4_MAXL = 8;
-constexpr size_t T4_LDS = (size_t)(T4_ZPX + T4_WIN + T4_SLACK) * 128;
+constexpr size_t t4_lds(int win) { return (size_t)(T4_ZPX + win + T4_SLACK) * 128; }
 constexpr int T4_BIG = 0x3fffffff;
 struct T4Item { int b, m, q0, qW, qH, ty, tx; };   // one work item: batch, head, query tile of level-map (qH x qW) at q0
 
@@ -100,8 +102,9 @@ __device__ unsigned long long g_t4_prof[16];
     }
 
 // __launch_bounds__(threads, waves per SIMD): two blocks per CU
-template <bool PROF, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 2) void msda_fwd_tiled4_kernel(
+// WIN: window budget in pixels, BPC: blocks per CU the launch is sized for (LDS = (ZPX + WIN + SLACK) * 128 B per block)
+template <bool PROF, int NW, int WIN = T4_WIN, int BPC = 2>
+__global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
     float *__restrict__ out)
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void msda_fwd_tiled4_kernel(
             const int x0 = __builtin_amdgcn_readfirstlane(row16_min(bw.z)), nx1 = __builtin_amdgcn_readfirstlane(row16_min(bw.w));
             const int wh = (-ny1 + 1) - y0 + 1, ww = (-nx1 + 1) - x0 + 1;   // rows y0 .. max(hl)+1, columns x0 .. max(wl)+1
             const int npix = wh * ww;
-            if (__builtin_expect(y0 == T4_BIG || npix > T4_WIN || ww > T4_ZPX - 2, 0)) {
+            if (__builtin_expect(y0 == T4_BIG || npix > WIN || ww > T4_ZPX - 2, 0)) {
                 // Cold (block-uniform): no accepted point at this level, or a window beyond the LDS budget.  The latter
                 // gathers the level from global memory in a compact ROLLED loop (locations / weights re-read from
                 // global, they are L2-hot): unrolled, this path was 1300 instructions in the middle of the hot loop.
@@ -438,21 +441,27 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T4_LDS);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T4_LDS);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<true, 4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T4_LDS);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 4, T4_WIN3, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN3));
         attr_set = true;
     }
-    const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
     const int mode = msda_tiled_enabled();
-#define T4_GO(PROF, NW)                                                                                               \
-    VLLM_LAUNCH((msda_fwd_tiled4_kernel<PROF, NW>), dim3(grid), dim3(NW * 64), T4_LDS, st, value, shapes, lsi, loc, attw, B, S, \
-                M, L, Lq, out)
-    if (mode == 5) T4_GO(true, 4);        // phase clock (diagnostics)
-    else if (mode == 2) T4_GO(false, 8);  // 8 waves per block
-    else T4_GO(false, 4);                 // default: 4 waves per block
+#define T4_GO(PROF, NW, WIN, BPC)                                                                                     \
+    VLLM_LAUNCH((msda_fwd_tiled4_kernel<PROF, NW, WIN, BPC>), dim3((cus / 8) * 8 * BPC), dim3(NW * 64), t4_lds(WIN), st, value, \
+                shapes, lsi, loc, attw, B, S, M, L, Lq, out)
+    // Window sizes at the cfg-4 encoder shape: median 108, mean 205, 90th percentile 308 pixels; 7.7 % of the (tile, level)
+    // pairs exceed 360 against 6.9 % that exceed 560 (coarse query level -> fine value level either way).  A 360-pixel
+    // budget is 52 KiB of LDS per block = THREE blocks per CU instead of two for 0.9 % more cold pairs: 582 vs 612 us.
+    // (256-pixel windows and FOUR blocks per CU: 727 us -- 14 % cold pairs cost more than the fourth block hides.)
+    if (mode == 5) T4_GO(true, 4, T4_WIN, 2);          // phase clock (diagnostics)
+    else if (mode == 2) T4_GO(false, 8, T4_WIN, 2);    // 8 waves per block, 2 blocks per CU
+    else if (mode == 8) T4_GO(false, 4, T4_WIN, 2);    // 4 waves per block, 560-pixel windows, 2 blocks per CU (608 us)
+    else T4_GO(false, 4, T4_WIN3, 3);                  // default: 360-pixel windows, 3 blocks per CU (583 us, same box)
 #undef T4_GO
     VLLM_CHECK_LAUNCH("msda_fwd_tiled4_kernel");
     return VLLM_OK;

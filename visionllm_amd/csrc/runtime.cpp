@@ -45,7 +45,7 @@ int msda_tiled_enabled()
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
         g_msda_tiled = e ? atoi(e) : 1;
-        if (g_msda_tiled < 0 || g_msda_tiled > 7) g_msda_tiled = 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 8) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -56,7 +56,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) {
         const int old = vllm::msda_tiled_enabled();
-        if (value < 0 || value > 7) { vllm::set_error("msda_tiled must be 0..7"); return VLLM_EINVAL; }
+        if (value < 0 || value > 8) { vllm::set_error("msda_tiled must be 0..8"); return VLLM_EINVAL; }
         vllm::g_msda_tiled = value;
         return old;
     }
