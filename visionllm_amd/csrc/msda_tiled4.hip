@@ -31,9 +31,9 @@ namespace {
 constexpr int T4_TH = 8, T4_TW = 16, T4_NQ = T4_TH * T4_TW;
 // Block shape: NW waves share one window.  A pass covers NW * 8 queries (8 lanes x 16 B = D 32 fp32 per query), so a
 // lane serves NPASS = 16 / NW queries per item ("steps") and evaluates the points of NOWN = NPASS / 2 of them itself.
-template <int NW>
+template <int NW, int TH = T4_TH>
 struct T4Shape {
-    static constexpr int THREADS = NW * 64, QPP = NW * 8, NPASS = T4_NQ / QPP, NOWN = NPASS / 2;
+    static constexpr int THREADS = NW * 64, QPP = NW * 8, NPASS = TH * T4_TW / QPP, NOWN = NPASS / 2;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 };
 constexpr int T4_ZPX = 48;                 // zero strip ahead of the window [pixels]; the pitch must stay <= ZPX - 2
@@ -103,15 +103,16 @@ __device__ unsigned long long g_t4_prof[16];
 
 // __launch_bounds__(threads, waves per SIMD): two blocks per CU
 // WIN: window budget in pixels, BPC: blocks per CU the launch is sized for (LDS = (ZPX + WIN + SLACK) * 128 B per block)
-template <bool PROF, int NW, int WIN = T4_WIN, int BPC = 2>
+// TH: query tile rows (tile = TH x 16 queries)
+template <bool PROF, int NW, int WIN = T4_WIN, int BPC = 2, int TH = T4_TH>
 __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
     float *__restrict__ out)
 {
     constexpr int D = 32, PT = 4;
-    constexpr int T4_THREADS = T4Shape<NW>::THREADS, T4_QPP = T4Shape<NW>::QPP, T4_NPASS = T4Shape<NW>::NPASS;
-    constexpr int NOWN = T4Shape<NW>::NOWN;
+    constexpr int T4_THREADS = T4Shape<NW, TH>::THREADS, T4_QPP = T4Shape<NW, TH>::QPP, T4_NPASS = T4Shape<NW, TH>::NPASS;
+    constexpr int NOWN = T4Shape<NW, TH>::NOWN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *win = reinterpret_cast<float *>(smem + T4_ZPX * 128);   // window pixel 0; the zero strip sits below it
     __shared__ int s_H[T4_MAXL], s_W[T4_MAXL], s_q0[T4_MAXL], s_tc[T4_MAXL + 1];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
             s_H[l] = H; s_W[l] = W; s_q0[l] = (int)cum; s_v0[l] = (long)lsi[l]; s_tc[l] = tc;
-            tc += ((H + T4_TH - 1) / T4_TH) * ((W + T4_TW - 1) / T4_TW);
+            tc += ((H + TH - 1) / TH) * ((W + T4_TW - 1) / T4_TW);
             cum += (long)H * W;
         }
         s_tc[L] = tc;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
     // (b, q, m) pair index of this lane's step (clamped to a live query) and whether the slot is live
     auto pair_of = [&](const T4Item &g, int step, bool &ok) -> unsigned {
         const int slot = ((step + NOWN * hq) & (T4_NPASS - 1)) * T4_QPP + slot0;
-        const int y = g.ty * T4_TH + slot / T4_TW, x = g.tx * T4_TW + slot % T4_TW;
+        const int y = g.ty * TH + slot / T4_TW, x = g.tx * T4_TW + slot % T4_TW;
         ok = y < g.qH && x < g.qW;
         const int q = g.q0 + (ok ? y : 0) * g.qW + (ok ? x : 0);
         return (unsigned)((g.b * Lq + q) * M + g.m);
@@ -457,7 +458,9 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
     // Window sizes at the cfg-4 encoder shape: median 108, mean 205, 90th percentile 308 pixels; 7.7 % of the (tile, level)
     // pairs exceed 360 against 6.9 % that exceed 560 (coarse query level -> fine value level either way).  A 360-pixel
     // budget is 52 KiB of LDS per block = THREE blocks per CU instead of two for 0.9 % more cold pairs: 582 vs 612 us.
-    // (256-pixel windows and FOUR blocks per CU: 727 us -- 14 % cold pairs cost more than the fourth block hides.)
+    // (256-pixel windows and FOUR blocks per CU: 727 us -- 14 % cold pairs cost more than the fourth block hides.  Other
+    // tile shapes through the TH template parameter: 16x16 queries / 560 pixels / 2 blocks 651 us, 4x16 queries / 256
+    // pixels / 4 blocks 587 us against 594 us for the default on the same box -- inside the noise, not adopted.)
     if (mode == 5) T4_GO(true, 4, T4_WIN, 2);          // phase clock (diagnostics)
     else if (mode == 2) T4_GO(false, 8, T4_WIN, 2);    // 8 waves per block, 2 blocks per CU
     else if (mode == 8) T4_GO(false, 4, T4_WIN, 2);    // 4 waves per block, 560-pixel windows, 2 blocks per CU (608 us)
