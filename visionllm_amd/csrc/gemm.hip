@@ -129,7 +129,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
 }
 
 int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st);   // gemm256.hip
-int gemm4w_bf16_launch(int epi, GemmArgs a, hipStream_t st);    // gemm4w.hip
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 {
@@ -143,7 +142,7 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
     VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
     if (a.variant == 4) { a.variant = 2; a.variant256 = 5; }   // 8-phase schedule on the 32x32x16 instruction
-    if (a.variant == 3) return gemm4w_bf16_launch(epi, a, st);
+    VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");
     if (a.variant != 1 && (a.variant == 2 || (a.N >= 1024 && a.M >= 1024)))
         return gemm256_bf16_launch(epi, a, st);
     a.mt = ceil_div(a.M, BM);
@@ -181,7 +180,6 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;   // VLLM_GEMM_FORCE_* (tests / tuning)
-    if (epilogue & 0x400) a.variant = 3;                         // VLLM_GEMM_FORCE_4W
     if (epilogue & 0x800) a.variant = 4;                         // VLLM_GEMM_FORCE_MF32
     if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }   // VLLM_GEMM_FORCE_192
     else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;

@@ -29,6 +29,10 @@
 namespace vllm {
 
 bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *out, const void *loc);
+int msda_tiled_enabled();   // runtime.cpp
+bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
+int msda_tiled6_launch_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                            const float *attw, int B, int S, int M, int L, int Lq, uint16_t *out, hipStream_t st);
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st);
 
@@ -84,8 +88,9 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
     const typename ValueIO<BF16>::elem_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ attw,
     int S, int M, int L, int P, long n_bq /* B*Lq */, long Lq, long n_chunks,
-    typename ValueIO<BF16>::elem_t *__restrict__ out)
+    typename ValueIO<BF16>::elem_t *__restrict__ out, int skip_pyramid)
 {
+    if (skip_pyramid && geometry_is_pyramid(shapes, L, Lq)) return;   // served by msda_tiled6.hip (launched ahead)
     typedef ValueIO<BF16> IO;
     typedef typename IO::elem_t elem_t;
     constexpr int CPL = IO::CPL;
@@ -412,7 +417,8 @@ static int cu_count()
 
 template <bool BF16, int LPG>
 static int launch_vec(const void *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                      const float *attw, int B, int S, int M, int L, int Lq, int P, void *out, hipStream_t st)
+                      const float *attw, int B, int S, int M, int L, int Lq, int P, void *out, hipStream_t st,
+                      int skip_pyramid = 0)
 {
     typedef typename ValueIO<BF16>::elem_t elem_t;
     constexpr int G = 64 / LPG;
@@ -427,7 +433,7 @@ static int launch_vec(const void *value, const int64_t *shapes, const int64_t *l
     const dim3 grid((unsigned)(want * 8)), block(MSDA_BLOCK);
 #define VLLM_MSDA_LAUNCH(PT)                                                                                   \
     VLLM_LAUNCH((msda_fwd_vec_kernel<BF16, LPG, PT>), grid, block, lds, st, (const elem_t *)value,      \
-                       shapes, lsi, loc, attw, S, M, L, P, n_bq, (long)Lq, n_chunks, (elem_t *)out)
+                       shapes, lsi, loc, attw, S, M, L, P, n_bq, (long)Lq, n_chunks, (elem_t *)out, skip_pyramid)
     if (P == 4) VLLM_MSDA_LAUNCH(4);
     else if (P == 8) VLLM_MSDA_LAUNCH(8);
     else if (P == 2) VLLM_MSDA_LAUNCH(2);
@@ -451,10 +457,11 @@ static bool vec_ok(int D, int CPL, int L, int P, const void *value, const void *
 
 template <bool BF16>
 static int dispatch_vec(int lpg, const void *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                        const float *attw, int B, int S, int M, int L, int Lq, int P, void *out, hipStream_t st)
+                        const float *attw, int B, int S, int M, int L, int Lq, int P, void *out, hipStream_t st,
+                        int skip_pyramid = 0)
 {
     switch (lpg) {
-#define C(N) case N: return launch_vec<BF16, N>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st)
+#define C(N) case N: return launch_vec<BF16, N>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, skip_pyramid)
         C(1); C(2); C(4); C(8); C(16); C(32); C(64);
 #undef C
     }
@@ -531,7 +538,13 @@ extern "C" int vllm_msda_forward_bf16(const uint16_t *value, const int64_t *shap
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_bf16: null pointer");
     VLLM_REQUIRE(vec_ok(D, 8, L, P, value, out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0,
                  "msda_forward_bf16: needs D in {8,16,...,512} (D/8 a power of two) and 16-byte aligned tensors (D=%d)", D);
-    return dispatch_vec<true>(D / 8, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // encoder self-attention shape on a pyramid: the LDS-tiled kernel (value converted to fp32 while it is staged); it
+    // returns at once for any other geometry and the gather kernel behind it then does the work
+    const bool t6 = msda_tiled_enabled() == 1 && msda_tiled6_ok(D, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw);
+    if (t6)
+        if (int e = msda_tiled6_launch_bf16(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st)) return e;
+    return dispatch_vec<true>(D / 8, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, t6 ? 1 : 0);
 }
 
 extern "C" int vllm_msda_sample_index_f32(const int64_t *shapes, const float *loc, int B, int M, int L, int Lq,

@@ -50,4 +50,22 @@ __device__ __forceinline__ SamplePoint<T> sample_point(T loc_w, T loc_h, int H, 
     return s;
 }
 
+// Do the level maps form an exact 2x pyramid (H_l * 2^l == H_0, W_l * 2^l == W_0) whose cells are the Lq queries?
+// Evaluated ON THE DEVICE from the shape tensor (block-uniform scalar loads), so that the launcher can enqueue the
+// pyramid kernel (msda_tiled6.hip) and its general-geometry fallback back to back without a host synchronisation:
+// exactly one of the two does the work.
+__device__ __forceinline__ bool geometry_is_pyramid(const int64_t *shapes, int L, long Lq)
+{
+    if (L < 1 || L > 4) return false;
+    const int H0 = (int)shapes[0], W0 = (int)shapes[1];
+    bool ok = H0 > 0 && W0 > 0;
+    long cum = (long)H0 * W0;
+    for (int l = 1; l < L; ++l) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        ok = ok && (Hl << l) == H0 && (Wl << l) == W0;
+        cum += (long)Hl * Wl;
+    }
+    return ok && cum == Lq;
+}
+
 }  // namespace vllm

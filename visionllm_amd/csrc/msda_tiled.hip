@@ -303,9 +303,6 @@ bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const 
            (reinterpret_cast<uintptr_t>(loc) & 7u) == 0;
 }
 
-int msda_pipe_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                     const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_pipe.hip
-
 template <typename Cfg>
 static int tiled_launch_cfg(int cus, const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                             const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st)
@@ -325,22 +322,28 @@ static int tiled_launch_cfg(int cus, const float *value, const int64_t *shapes, 
 }
 
 int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                       const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_tiled4.hip
+                       const float *attw, int B, int S, int M, int L, int Lq, float *out, int skip_pyramid,
+                       hipStream_t st);   // msda_tiled4.hip
+bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
+int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                       int B, int S, int M, int L, int Lq, float *out, hipStream_t st);
 
-int msda_tiled5_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                       const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st);   // msda_tiled5.hip
-
+// "msda_tiled": 0 gather kernel, 1 automatic (default), 2 generation 4 with 8 waves, 3 generation 2, 5 generation 4 with
+// the phase clock, 8 generation 4 / 560-pixel windows / 2 blocks per CU, 9 generation 4 / 360 / 3 (the round-1 default).
+// Automatic: generation 6 (msda_tiled6.hip) does the work when the level maps form an exact 2x pyramid -- it checks that on
+// the device, from the shape tensor, and returns at once otherwise -- and the generation-4 launch behind it skips pyramids,
+// so exactly one of the two runs whatever the geometry, without a host synchronisation.
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
     const int mode = msda_tiled_enabled();
-    // generation 4 keeps pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
+    // generations 4 / 6 keep pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
-    if ((mode == 6 || mode == 7) && fits32 && (reinterpret_cast<uintptr_t>(loc) & 15u) == 0)
-        return msda_tiled5_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    if ((mode == 1 || mode == 2 || mode == 5 || mode == 6 || mode == 7 || mode == 8) && fits32)
-        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    if (mode == 4) return msda_pipe_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 1 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
+        if (int e = msda_tiled6_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st)) return e;
+        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
+    }
+    if (mode != 3 && fits32) return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, st);
     static int cus = 0;
     if (cus == 0) {
         hipDeviceProp_t prop;
@@ -348,7 +351,6 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    (void)P;
     return tiled_launch_cfg<MTCfg<8, 16, 560, 2>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
 }
 

@@ -108,9 +108,10 @@ template <bool PROF, int NW, int WIN = T4_WIN, int BPC = 2, int TH = T4_TH>
 __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
-    float *__restrict__ out)
+    float *__restrict__ out, int skip_pyramid)
 {
     constexpr int D = 32, PT = 4;
+    if (skip_pyramid && geometry_is_pyramid(shapes, L, Lq)) return;   // served by the generation-6 kernel launched ahead of this one
     constexpr int T4_THREADS = T4Shape<NW, TH>::THREADS, T4_QPP = T4Shape<NW, TH>::QPP, T4_NPASS = T4Shape<NW, TH>::NPASS;
     constexpr int NOWN = T4Shape<NW, TH>::NOWN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
 }  // namespace
 
 int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                       const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st)
+                       const float *attw, int B, int S, int M, int L, int Lq, float *out, int skip_pyramid,
+                       hipStream_t st)
 {
     static int cus = 0;
     if (cus == 0) {
@@ -454,7 +456,7 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
     const int mode = msda_tiled_enabled();
 #define T4_GO(PROF, NW, WIN, BPC)                                                                                     \
     VLLM_LAUNCH((msda_fwd_tiled4_kernel<PROF, NW, WIN, BPC>), dim3((cus / 8) * 8 * BPC), dim3(NW * 64), t4_lds(WIN), st, value, \
-                shapes, lsi, loc, attw, B, S, M, L, Lq, out)
+                shapes, lsi, loc, attw, B, S, M, L, Lq, out, skip_pyramid)
     // Window sizes at the cfg-4 encoder shape: median 108, mean 205, 90th percentile 308 pixels; 7.7 % of the (tile, level)
     // pairs exceed 360 against 6.9 % that exceed 560 (coarse query level -> fine value level either way).  A 360-pixel
     // budget is 52 KiB of LDS per block = THREE blocks per CU instead of two for 0.9 % more cold pairs: 582 vs 612 us.
@@ -464,7 +466,7 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
     if (mode == 5) T4_GO(true, 4, T4_WIN, 2);          // phase clock (diagnostics)
     else if (mode == 2) T4_GO(false, 8, T4_WIN, 2);    // 8 waves per block, 2 blocks per CU
     else if (mode == 8) T4_GO(false, 4, T4_WIN, 2);    // 4 waves per block, 560-pixel windows, 2 blocks per CU (608 us)
-    else T4_GO(false, 4, T4_WIN3, 3);                  // default: 360-pixel windows, 3 blocks per CU (583 us, same box)
+    else T4_GO(false, 4, T4_WIN3, 3);                  // 360-pixel windows, 3 blocks per CU (583 us, same box)
 #undef T4_GO
     VLLM_CHECK_LAUNCH("msda_fwd_tiled4_kernel");
     return VLLM_OK;

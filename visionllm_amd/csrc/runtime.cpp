@@ -36,7 +36,7 @@ int gemm_variant_override()
     if (g_gemm_variant < 0) {
         const char *e = getenv("VLLM_GEMM_VARIANT");
         g_gemm_variant = e ? atoi(e) : 0;
-        if (g_gemm_variant < 0 || g_gemm_variant > 4) g_gemm_variant = 0;
+        if (g_gemm_variant < 0 || g_gemm_variant > 4 || g_gemm_variant == 3) g_gemm_variant = 0;
     }
     return g_gemm_variant;
 }
@@ -45,7 +45,7 @@ int msda_tiled_enabled()
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
         g_msda_tiled = e ? atoi(e) : 1;
-        if (g_msda_tiled < 0 || g_msda_tiled > 8) g_msda_tiled = 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 9 || g_msda_tiled == 4 || g_msda_tiled == 6 || g_msda_tiled == 7) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -56,7 +56,10 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) {
         const int old = vllm::msda_tiled_enabled();
-        if (value < 0 || value > 8) { vllm::set_error("msda_tiled must be 0..8"); return VLLM_EINVAL; }
+        if (value < 0 || value > 9 || value == 4 || value == 6 || value == 7) {
+            vllm::set_error("msda_tiled must be one of 0, 1, 2, 3, 5, 8, 9");
+            return VLLM_EINVAL;
+        }
         vllm::g_msda_tiled = value;
         return old;
     }
@@ -64,7 +67,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 127; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
-        if (value < 0 || value > 4) { vllm::set_error("gemm_variant must be 0..4"); return VLLM_EINVAL; }
+        if (value < 0 || value > 4 || value == 3) { vllm::set_error("gemm_variant must be 0, 1, 2 or 4"); return VLLM_EINVAL; }
         vllm::g_gemm_variant = value;
         return old;
     }
