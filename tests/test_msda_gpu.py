@@ -114,7 +114,7 @@ def test_tiled_kernel_matches_gather_kernel(mode):
     try:
         plain = _run(g)
         ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-        for variant in (1, 2, 3, 5, 8, 9):  # automatic (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
+        for variant in (1, 17, 2, 3, 5, 8, 9):  # automatic (generation 7 on pyramids, else 4); 17: generation 6; (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
             _lib.set_option("msda_tiled", variant)
             tiled = _run(g)
             again = _run(g)
@@ -159,15 +159,17 @@ def test_generation6_pyramid_items(name, mode):
     old = _lib.set_option("msda_tiled", 0)
     try:
         plain = _run(g)
-        _lib.set_option("msda_tiled", 1)
-        t6 = _run(g)
-        again = _run(g)
+        res = {}
+        for variant in (1, 17):   # automatic = generation 7 (software pipeline across items); generation 6
+            _lib.set_option("msda_tiled", variant)
+            res[variant] = (_run(g), _run(g))
     finally:
         _lib.set_option("msda_tiled", old)
-    assert torch.equal(t6, again), "race: two runs of the same kernel differ"
-    assert torch.isfinite(t6).all()
-    torch.testing.assert_close(t6, plain, rtol=2e-6, atol=2e-6)
-    np.testing.assert_allclose(t6.cpu().numpy(), ref, rtol=4e-6, atol=4e-6)
+    for variant, (t6, again) in res.items():
+        assert torch.equal(t6, again), f"race: two runs of kernel variant {variant} differ"
+        assert torch.isfinite(t6).all()
+        torch.testing.assert_close(t6, plain, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(t6.cpu().numpy(), ref, rtol=4e-6, atol=4e-6)
 
 
 def test_generation6_bf16_value():
@@ -228,7 +230,7 @@ def test_nan_and_inf_sampling_locations_contribute_nothing():
     flat[12::59] = -np.inf
     ref = O.forward(g["value"], g["shapes"], g["lsi"], loc, g["attw"])
     assert np.isfinite(ref).all()
-    for tiled in (0, 1, 2, 3, 8, 9):
+    for tiled in (0, 1, 17, 2, 3, 8, 9):
         old = _lib.set_option("msda_tiled", tiled)
         try:
             out = A.ms_deform_attn_forward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]), 64)

@@ -51,12 +51,12 @@ def main():
                     t[k] = t[k] + 0.01 * torch.randn_like(t[k])
             B, S, M, D = t["value"].shape
             Lq, L, P = t["loc"].shape[1], t["loc"].shape[3], t["loc"].shape[4]
-            for dt in ("f32_auto", "f32_gen4", "f32_gen4_560", "f32_gen2", "f32_gather", "bf16_auto", "bf16_gather"):
+            for dt in ("f32_auto", "f32_gen6", "f32_gen4", "f32_gen2", "f32_gather", "bf16_auto", "bf16_gather"):
                 v = t["value"] if not dt.startswith("bf16") else t["value"].bfloat16()
                 from visionllm_amd import _lib
-                # f32_auto / bf16_auto: generation 6 on pyramids (msda_tiled6.hip), generation 4 / gather kernel otherwise
+                # f32_auto: generation 7 on pyramids (msda_tiled7.hip), generation 4 otherwise; bf16_auto: generation 6 / gather kernel
                 _lib.set_option("msda_tiled", {"f32_gather": 0, "bf16_gather": 0, "f32_auto": 1, "f32_gen4_w8": 2, "f32_gen2": 3,
-                                               "f32_gen4_560": 8, "f32_gen4": 9}.get(dt, 1))
+                                               "f32_gen4_560": 8, "f32_gen4": 9, "f32_gen6": 17}.get(dt, 1))
                 sec = timeit(lambda: A.ms_deform_attn_forward(v, t["shapes"], t["lsi"], t["loc"], t["attw"], 64), a.iters)
                 ab = algorithmic_bytes(B, S, M, D, L, Lq, P, 2 if dt.startswith("bf16") else 4)
                 gathered = B * Lq * M * L * P * 4 * D * (2 if dt.startswith("bf16") else 4)

@@ -325,21 +325,30 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                        const float *attw, int B, int S, int M, int L, int Lq, float *out, int skip_pyramid,
                        hipStream_t st);   // msda_tiled4.hip
 bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
+int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st);   // msda_tiled7.hip
 int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, hipStream_t st);
 
 // "msda_tiled": 0 gather kernel, 1 automatic (default), 2 generation 4 with 8 waves, 3 generation 2, 5 generation 4 with
-// the phase clock, 8 generation 4 / 560-pixel windows / 2 blocks per CU, 9 generation 4 / 360 / 3 (the round-1 default).
-// Automatic: generation 6 (msda_tiled6.hip) does the work when the level maps form an exact 2x pyramid -- it checks that on
-// the device, from the shape tensor, and returns at once otherwise -- and the generation-4 launch behind it skips pyramids,
-// so exactly one of the two runs whatever the geometry, without a host synchronisation.
+// the phase clock, 8 generation 4 / 560-pixel windows / 2 blocks per CU, 9 generation 4 / 360 / 3 (the round-1 default),
+// 10-14 generation 6 (10 / 14 phase clock, 11-13 gather / staging variants), 15 generation 7, 16 generation 7 + phase clock,
+// 17 generation 6.
+// Automatic: generation 7 (msda_tiled7.hip: pyramid items, software pipeline across items) does the work when the level
+// maps form an exact 2x pyramid -- it checks that on the device, from the shape tensor, and returns at once otherwise -- and
+// the generation-4 launch behind it skips pyramids, so exactly one of the two runs whatever the geometry, without a host
+// synchronisation.
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
 {
     const int mode = msda_tiled_enabled();
     // generations 4 / 6 keep pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
-    if (mode == 1 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
+    if ((mode == 1 || mode == 15 || mode == 16) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
+        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st)) return e;
+        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
+    }
+    if (mode >= 10 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
         if (int e = msda_tiled6_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st)) return e;
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
     }

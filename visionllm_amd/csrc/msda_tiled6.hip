@@ -32,63 +32,11 @@
 #include <stdlib.h>
 #include "kernels.hpp"
 #include "msda_sample.hpp"
+#include "msda_tiled6_helpers.hpp"
 
 namespace vllm {
 
 namespace {
-
-constexpr int T6_ZPX = 48;               // zero strip at the bottom of LDS [pixels]; a window's pitch must stay <= ZPX - 2
-constexpr int T6_BIG = 0x3fffffff;
-constexpr int T6_SLACK = 8;              // windows are padded to 8 pixels (the last DMA instruction writes whole groups)
-
-__device__ __attribute__((aligned(128))) float g_t6_zero_px[32];   // zero-initialised: DMA source of out-of-image pixels
-
-template <int K>
-__device__ __forceinline__ int qbi(int x)   // value of lane K of this lane's quad
-{
-    return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, true);
-}
-template <int K>
-__device__ __forceinline__ float qbf(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, true));
-}
-// acc += (w of quad lane K) * v in ONE VALU instruction
-template <int K>
-__device__ __forceinline__ void fmac_q(float &acc, float w, float v)
-{
-    static_assert(K >= 0 && K < 4, "quad lane");
-    if constexpr (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
-    if constexpr (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
-    if constexpr (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
-    if constexpr (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_min(int v)   // min(v, v of the lane CTRL selects); row_ror keeps lane & 3
-{
-    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int sel4(int k, int a0, int a1, int a2, int a3)
-{
-    return k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p)   // LDS byte address of a __shared__ object
-{
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-// 16 bytes of fp32 channels from a value row of either storage type (cold path)
-__device__ __forceinline__ float4_t load4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }
-__device__ __forceinline__ float4_t load4(const uint16_t *p)
-{
-    const uint2_t r = *reinterpret_cast<const uint2_t *>(p);
-    return (float4_t){bf16lo_to_f32(r.x), bf16hi_to_f32(r.x), bf16lo_to_f32(r.y), bf16hi_to_f32(r.y)};
-}
-__device__ __forceinline__ void store4(float *p, float4_t v) { *reinterpret_cast<float4_t *>(p) = v; }
-__device__ __forceinline__ void store4(uint16_t *p, float4_t v)
-{
-    *reinterpret_cast<uint2_t *>(p) = (uint2_t){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-}
 
 struct T6Item { int b, m, lq, ty, tx; };   // batch, head, (flat: query level), tile row / column
 
@@ -135,13 +83,24 @@ __device__ __forceinline__ void stage_window(const float *vl, char *dst, int y0,
         }
     }
 }
-// bf16 value: 8 lanes x 8 B per pixel through registers, converted to fp32 on the way (same LDS image); four rounds of
-// loads are in flight before the first conversion.
-template <int NW>
-__device__ __forceinline__ void stage_window(const uint16_t *vl, char *dst, int y0, int x0, int wh, int ww, int H, int W,
-                                             unsigned MD, int wave_s, int lane)
+// Register-staged alternative (bf16 value always; fp32 value when STG == 1): 8 lanes per pixel, UN rounds of loads in flight
+// before the first LDS write; bf16 is converted to fp32 on the way (same LDS image).
+__device__ __forceinline__ float4_t t6_ld_px(const float *p, bool inside)
 {
-    constexpr int QPP = NW * 8, UN = 2;
+    const float4_t t = *reinterpret_cast<const float4_t *>(p);
+    return inside ? t : (float4_t){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ float4_t t6_ld_px(const uint16_t *p, bool inside)
+{
+    const uint2_t r = *reinterpret_cast<const uint2_t *>(p);
+    const float4_t t = {bf16lo_to_f32(r.x), bf16hi_to_f32(r.x), bf16lo_to_f32(r.y), bf16hi_to_f32(r.y)};
+    return inside ? t : (float4_t){0.f, 0.f, 0.f, 0.f};
+}
+template <int NW, int UN, typename VT>
+__device__ __forceinline__ void stage_window_regs(const VT *vl, char *dst, int y0, int x0, int wh, int ww, int H, int W,
+                                                  unsigned MD, int wave_s, int lane)
+{
+    constexpr int QPP = NW * 8;
     const int npix = wh * ww;
     const int sub = lane & 7;
     const unsigned magic = (1u << 20) / (unsigned)ww + 1u;
@@ -150,34 +109,47 @@ __device__ __forceinline__ void stage_window(const uint16_t *vl, char *dst, int 
     const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
     int gy = y0 + wy, gx = x0 + wx;
     const int xend = x0 + ww;
-    const uint16_t *vlb = vl + sub * 4;
-    char *wdst = dst + pix * 128 + sub * 16;
+    const VT *vlb = vl + sub * 4;
+    char *wdst = dst + (lane >> 3) * 128 + sub * 16;
     for (int i0 = wave_s * 8; i0 < npix; i0 += QPP * UN) {
-        uint2_t r[UN];
+        float4_t r[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && i0 + u * QPP < npix;
-            const unsigned off = inside ? (unsigned)(gy * W + gx) * MD : 0u;
-            const uint2_t t = *reinterpret_cast<const uint2_t *>(vlb + off);
-            r[u] = inside ? t : (uint2_t){0u, 0u};
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned off = inside ? (unsigned)(gy * W + gx) * MD : 0u;   // (outside the map: any mapped address; the value is dropped)
+            r[u] = t6_ld_px(vlb + off, inside);
             gx += dr; gy += dq;
             if (gx >= xend) { gx -= ww; ++gy; }
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (i0 + u * QPP < npix) {   // (wave-uniform) whole 8-pixel groups; the tail lands in the window's padding
-                const float4_t f = {bf16lo_to_f32(r[u].x), bf16hi_to_f32(r[u].x), bf16lo_to_f32(r[u].y), bf16hi_to_f32(r[u].y)};
-                *reinterpret_cast<float4_t *>(wdst + (size_t)(i0 - wave_s * 8 + u * QPP) * 128) = f;
-            }
-        }
+        for (int u = 0; u < UN; ++u)
+            if (i0 + u * QPP < npix)   // (wave-uniform) whole 8-pixel groups; the tail lands in the window's padding
+                *reinterpret_cast<float4_t *>(wdst + (size_t)(i0 + u * QPP) * 128) = r[u];
     }
+}
+template <int NW>
+__device__ __forceinline__ void stage_window(const uint16_t *vl, char *dst, int y0, int x0, int wh, int ww, int H, int W,
+                                             unsigned MD, int wave_s, int lane)
+{
+    stage_window_regs<NW, 4>(vl, dst, y0, x0, wh, ww, H, W, MD, wave_s, lane);
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------
 // NW waves per block, NPASS passes of NW * 16 (query, head) pairs per item, WIN arena pixels, BPC blocks per CU.
 // The kernel serves exact pyramids only (checked here, from the device-side shapes: no host sync); for any other geometry it
 // returns at once and the generation-4 kernel launched behind it does the work (msda_tiled6_launch).
-template <typename VT, typename OT, int NW, int NPASS, int WIN, int BPC>
+// Phase clock ("msda_tiled" option 10): wave 0 of every block adds the shader-clock ticks it spends in each phase.
+__device__ unsigned long long g_t6_prof[16];
+#define T6_TICK(slot)                                                            \
+    if (PROF) {                                                                  \
+        const unsigned now__ = (unsigned)__builtin_amdgcn_s_memtime();           \
+        pacc[slot] += now__ - tprev;                                             \
+        tprev = now__;                                                           \
+    }
+
+// GV (gather arithmetic, for A/B): 0 v_fmac_f32_dpp (weights broadcast inside the multiply-add), 1 DPP moves + v_pk_fma_f32,
+// 2 DPP moves + v_fma_f32
+template <typename VT, typename OT, int NW, int NPASS, int WIN, int BPC, bool PROF = false, int GV = 0, int STG = 0>
 __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
@@ -191,6 +163,8 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
 
     if (!geometry_is_pyramid(shapes, L, Lq)) return;
     const int tid = threadIdx.x, lane = tid & 63;
+    unsigned pacc[16] = {};   // (dead in the production instantiation)
+    unsigned tprev = PROF ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = lane & 3;                       // the value level this lane owns
     const unsigned MD = (unsigned)(M * D);
@@ -269,6 +243,7 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
     }
     int par = 0;
     while (have) {
+        T6_TICK(0)   // previous item's stores, loop control
         // ---- S1: this lane's 4 points per pass (level k): weights x attention weight, corner box ----
         float w1[NPASS][4], w2[NPASS][4], w3[NPASS][4], w4[NPASS][4];
         int o[NPASS][4];               // (h_low + 1) << 16 | (w_low + 1); replaced by the LDS byte offset when level k is hot (S5)
@@ -292,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
                 r2 = min(r2, ok ? sp.w_low : T6_BIG); r3 = min(r3, ok ? -sp.w_low : T6_BIG);
             }
         }
+        T6_TICK(1)   // wait for the prefetched locations + point arithmetic
         // ---- S2: boxes of all levels: lanes of equal (lane & 3) inside a row of 16, then LDS integer minima ----
         r0 = dpp_min<0x128>(dpp_min<0x124>(r0)); r1 = dpp_min<0x128>(dpp_min<0x124>(r1));   // row_ror:4, row_ror:8
         r2 = dpp_min<0x128>(dpp_min<0x124>(r2)); r3 = dpp_min<0x128>(dpp_min<0x124>(r3));
@@ -302,7 +278,9 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
                          :: "v"(a), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T6_TICK(2)   // box reduction
         __syncthreads();   // (B) boxes complete; every wave has finished gathering from the arena
+        T6_TICK(3)   // barrier B
         const int4 bx = *reinterpret_cast<const int4 *>(boxp + k * 4);   // lane l < 4: the box of level l
         if (tid < 16) s_box[(par ^ 1) * 16 + tid] = T6_BIG;   // (the other buffer was read for the last time before this barrier)
         par ^= 1;
@@ -349,6 +327,7 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[p][c] = 0.f;
+        T6_TICK(4)   // arena layout, offsets
 
         // the next item
         j += blocks_per_xcd;
@@ -367,18 +346,26 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
                     const int y0 = __builtin_amdgcn_readlane(bx.x, l), ny1 = __builtin_amdgcn_readlane(bx.y, l);
                     const int x0 = __builtin_amdgcn_readlane(bx.z, l), nx1 = __builtin_amdgcn_readlane(bx.w, l);
                     const int v0l = __builtin_amdgcn_readlane(v0k, l);
-                    stage_window<NW>(vb + (size_t)v0l * MD, arena + (lay_l & 0xffff) * 128, y0, x0, (-ny1 + 1) - y0 + 1,
-                                     (-nx1 + 1) - x0 + 1, H0 >> l, W0 >> l, MD, wave_s, lane);
+                    if constexpr (STG == 1)
+                        stage_window_regs<NW, 6>(vb + (size_t)v0l * MD, arena + (lay_l & 0xffff) * 128, y0, x0, (-ny1 + 1) - y0 + 1,
+                                                 (-nx1 + 1) - x0 + 1, H0 >> l, W0 >> l, MD, wave_s, lane);
+                    else
+                        stage_window<NW>(vb + (size_t)v0l * MD, arena + (lay_l & 0xffff) * 128, y0, x0, (-ny1 + 1) - y0 + 1,
+                                         (-nx1 + 1) - x0 + 1, H0 >> l, W0 >> l, MD, wave_s, lane);
                 }
             }
+            T6_TICK(5)   // DMA issue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            T6_TICK(6)   // own DMA landed
             __syncthreads();   // (C) windows complete
+            T6_TICK(7)   // barrier C
             if (g == 0) {      // next item's locations / weights: in flight during the gather
                 if (have_next) decode(xcd * ipx + j, nb, nm, nty, ntx);
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p) npr[p] = pair_of(nb, nm, nty, ntx, p, nqok[p]);
                 fetch(npr);
             }
+            T6_TICK(8)   // next item: decode + prefetch issue
             // ---- S6: gather.  Level LQ's owner is quad lane LQ: offset and weights arrive by DPP inside the consumer ----
 #define T6_HOT_POINT(P_, I_, LQ)                                                                                 \
     {                                                                                                            \
@@ -388,13 +375,34 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
         const float4_t a3 = *reinterpret_cast<const float4_t *>(s0 + pitch), a4 = *reinterpret_cast<const float4_t *>(s0 + pitch + 128); \
         const float4_t c1 = *reinterpret_cast<const float4_t *>(s1), c2 = *reinterpret_cast<const float4_t *>(s1 + 128); \
         const float4_t c3 = *reinterpret_cast<const float4_t *>(s1 + pitch), c4 = *reinterpret_cast<const float4_t *>(s1 + pitch + 128); \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
-            fmac_q<LQ>(acc[P_][c], w1[P_][I_], a1[c]); fmac_q<LQ>(acc[P_][c], w2[P_][I_], a2[c]);                \
-            fmac_q<LQ>(acc[P_][c], w3[P_][I_], a3[c]); fmac_q<LQ>(acc[P_][c], w4[P_][I_], a4[c]);                \
-        }                                                                                                        \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
-            fmac_q<LQ>(acc[P_][4 + c], w1[P_][I_], c1[c]); fmac_q<LQ>(acc[P_][4 + c], w2[P_][I_], c2[c]);        \
-            fmac_q<LQ>(acc[P_][4 + c], w3[P_][I_], c3[c]); fmac_q<LQ>(acc[P_][4 + c], w4[P_][I_], c4[c]);        \
+        if constexpr (GV == 0) {                                                                                 \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+                fmac_q<LQ>(acc[P_][c], w1[P_][I_], a1[c]); fmac_q<LQ>(acc[P_][c], w2[P_][I_], a2[c]);            \
+                fmac_q<LQ>(acc[P_][c], w3[P_][I_], a3[c]); fmac_q<LQ>(acc[P_][c], w4[P_][I_], a4[c]);            \
+            }                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+                fmac_q<LQ>(acc[P_][4 + c], w1[P_][I_], c1[c]); fmac_q<LQ>(acc[P_][4 + c], w2[P_][I_], c2[c]);    \
+                fmac_q<LQ>(acc[P_][4 + c], w3[P_][I_], c3[c]); fmac_q<LQ>(acc[P_][4 + c], w4[P_][I_], c4[c]);    \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            const float e1 = qbf<LQ>(w1[P_][I_]), e2 = qbf<LQ>(w2[P_][I_]), e3 = qbf<LQ>(w3[P_][I_]), e4 = qbf<LQ>(w4[P_][I_]); \
+            if constexpr (GV == 1) {                                                                             \
+                _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                               \
+                    float2_t t = {acc[P_][c], acc[P_][c + 1]};                                                   \
+                    t = t6_fma2(e1, (float2_t){a1[c], a1[c + 1]}, t); t = t6_fma2(e2, (float2_t){a2[c], a2[c + 1]}, t); \
+                    t = t6_fma2(e3, (float2_t){a3[c], a3[c + 1]}, t); t = t6_fma2(e4, (float2_t){a4[c], a4[c + 1]}, t); \
+                    acc[P_][c] = t.x; acc[P_][c + 1] = t.y;                                                      \
+                    float2_t u = {acc[P_][4 + c], acc[P_][5 + c]};                                               \
+                    u = t6_fma2(e1, (float2_t){c1[c], c1[c + 1]}, u); u = t6_fma2(e2, (float2_t){c2[c], c2[c + 1]}, u); \
+                    u = t6_fma2(e3, (float2_t){c3[c], c3[c + 1]}, u); u = t6_fma2(e4, (float2_t){c4[c], c4[c + 1]}, u); \
+                    acc[P_][4 + c] = u.x; acc[P_][5 + c] = u.y;                                                  \
+                }                                                                                                \
+            } else {                                                                                             \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                  \
+                    acc[P_][c] = fmaf(e4, a4[c], fmaf(e3, a3[c], fmaf(e2, a2[c], fmaf(e1, a1[c], acc[P_][c])))); \
+                    acc[P_][4 + c] = fmaf(e4, c4[c], fmaf(e3, c3[c], fmaf(e2, c2[c], fmaf(e1, c1[c], acc[P_][4 + c])))); \
+                }                                                                                                \
+            }                                                                                                    \
         }                                                                                                        \
     }
 #define T6_LEVEL(LQ)                                                                                             \
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
         }                                                                                                        \
     }
             T6_LEVEL(0) T6_LEVEL(1) T6_LEVEL(2) T6_LEVEL(3)
+            T6_TICK(9)   // gather
 #undef T6_LEVEL
 #undef T6_HOT_POINT
             // Cold levels of this group (window beyond the arena): the same lanes gather from global memory, one point at
@@ -446,8 +455,12 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (PROF) pacc[12] += 1;
             }
+            T6_TICK(10)   // cold levels
+            if (PROF) pacc[13] += 1;   // groups
         }
+        if (PROF) pacc[14] += 1;       // items
         // ---- output: 2 x 16 bytes per lane ----
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
@@ -461,21 +474,25 @@ __global__ __launch_bounds__(NW * 64, (NW * BPC + 3) / 4) void msda_fwd_tiled6_k
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) { pr[p] = npr[p]; qok[p] = nqok[p]; }
     }
+    if (PROF && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_t6_prof[i], (unsigned long long)pacc[i]);
+    }
 }
 
-template <typename VT, typename OT, int NW, int NPASS, int WIN, int BPC>
+template <typename VT, typename OT, int NW, int NPASS, int WIN, int BPC, bool PROF = false, int GV = 0, int STG = 0>
 int t6_go(int cus, const VT *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B,
           int S, int M, int L, int Lq, OT *out, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(T6_ZPX + WIN + T6_SLACK) * 128 + 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC, PROF, GV, STG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    VLLM_LAUNCH((msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC>), dim3((cus / 8) * 8 * BPC), dim3(NW * 64), lds, st, value,
-                shapes, lsi, loc, attw, B, S, M, L, Lq, out);
+    VLLM_LAUNCH((msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC, PROF, GV, STG>), dim3((cus / 8) * 8 * BPC), dim3(NW * 64), lds, st,
+                value, shapes, lsi, loc, attw, B, S, M, L, Lq, out);
     VLLM_CHECK_LAUNCH("msda_fwd_tiled6_kernel");
     return VLLM_OK;
 }
@@ -505,13 +522,32 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
                        int B, int S, int M, int L, int Lq, float *out, hipStream_t st)
 {
     // 6 waves x 2 passes = 192 (query, head) slots for the 170 queries of an item; 560-pixel arena, 2 blocks per CU
-    return t6_go<float, float, 6, 2, 560, 2>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    const int mode = msda_tiled_enabled();
+    if (mode == 10) return t6_go<float, float, 6, 2, 560, 2, true>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 11) return t6_go<float, float, 6, 2, 560, 2, false, 1>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 12) return t6_go<float, float, 6, 2, 560, 2, false, 2>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 13) return t6_go<float, float, 6, 2, 560, 2, false, 1, 1>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (mode == 14) return t6_go<float, float, 6, 2, 560, 2, true, 1, 1>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    return t6_go<float, float, 6, 2, 560, 2, false, 1>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
 }
 
 int msda_tiled6_launch_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                             const float *attw, int B, int S, int M, int L, int Lq, uint16_t *out, hipStream_t st)
 {
-    return t6_go<uint16_t, uint16_t, 6, 2, 560, 2>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    return t6_go<uint16_t, uint16_t, 6, 2, 560, 2, false, 1>(t6_cus(), value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+}
+
+int msda6_debug_counters(long *out, int n)
+{
+    unsigned long long h[16];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_t6_prof), sizeof(h)) != hipSuccess) {
+        set_error("msda6_debug_counters: device read failed");
+        return VLLM_ELAUNCH;
+    }
+    for (int i = 0; i < n && i < 16; ++i) out[i] = (long)h[i];
+    const unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t6_prof), z, sizeof(z));
+    return n < 16 ? n : 16;
 }
 
 }  // namespace vllm

@@ -45,7 +45,7 @@ int msda_tiled_enabled()
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
         g_msda_tiled = e ? atoi(e) : 1;
-        if (g_msda_tiled < 0 || g_msda_tiled > 9 || g_msda_tiled == 4 || g_msda_tiled == 6 || g_msda_tiled == 7) g_msda_tiled = 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 17 || g_msda_tiled == 4 || g_msda_tiled == 6 || g_msda_tiled == 7) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -56,8 +56,8 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) {
         const int old = vllm::msda_tiled_enabled();
-        if (value < 0 || value > 9 || value == 4 || value == 6 || value == 7) {
-            vllm::set_error("msda_tiled must be one of 0, 1, 2, 3, 5, 8, 9");
+        if (value < 0 || value > 17 || value == 4 || value == 6 || value == 7) {
+            vllm::set_error("msda_tiled must be one of 0, 1, 2, 3, 5, 8, 9, 10..17");
             return VLLM_EINVAL;
         }
         vllm::g_msda_tiled = value;
@@ -74,11 +74,12 @@ extern "C" int vllm_set_option(const char *name, int value)
     vllm::set_error("unknown option %s", name);
     return VLLM_EINVAL;
 }
-namespace vllm { int msda_debug_counters(long *out, int n); }
+namespace vllm { int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda7_debug_counters(long *out, int n); }
 extern "C" int vllm_debug_counters(long *out, int n)
 {
     if (!out || n <= 0) { vllm::set_error("vllm_debug_counters: bad arguments"); return VLLM_EINVAL; }
-    return vllm::msda_debug_counters(out, n);
+    const int mode = vllm::msda_tiled_enabled();
+    return mode >= 15 ? vllm::msda7_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
 }
 extern "C" int vllm_abi_version(void) { return VLLM_ABI_VERSION; }
 extern "C" const char *vllm_last_error(void) { return vllm::g_err; }
