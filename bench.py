@@ -2,7 +2,8 @@
 """Hot-path benchmark: images/sec of the image -> visual-token path + MSDA forward on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N>1: the driver launches `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+     bench.py --gpus N ...`; started WITHOUT a launcher, `python bench.py --gpus N` re-executes itself under that launcher.)
 
 One "step" = one pass of the hot path over one batch of synthetic input PER RANK (weak scaling):
   workload "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4" (BASELINE.json metric; configs[1] arch + configs[3] shapes)
@@ -14,8 +15,12 @@ One "step" = one pass of the hot path over one batch of synthetic input PER RANK
       B=8: 6 encoder-shaped calls (Lq = S = 37485) + 6 decoder-shaped calls (Lq = 900), fp32 (the reference upcasts).
 Weights are random-init (no network), inputs synthetic and resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0): metric/value/unit + "roofline" (dominant kernel) + "rooflines" (the three kernels the
-north star names) + "cpu_baseline" (the oracle timed on the host cores, bounded sample, N=1 only).
+Everything of a step is enqueued on ONE stream (--msda-stream 1 puts the det-head MSDA calls on a side stream: valid only
+as cross-batch pipelining).
+Prints ONE JSON line (rank 0): metric/value/unit + "roofline" (the kernel with the largest measured share of a step) +
+"rooflines" (every hot kernel, each timed alone with HIP events on the stream the C ABI launches on) + "phases_ms"
+(ViT+projector / token all-gather / MSDA, max over ranks) + "cpu_baseline" (reference CPU path on the host cores: 1 warm-up
++ 3 repetitions, median, bounded sample; N=1 only).
 """
 import argparse
 import json
@@ -57,7 +62,7 @@ def build_intern_model(dev):
                 if p.dim() >= 2:
                     p.normal_(0, 0.02)
         bridge = build_vl_bridge("internvl_mlp", IVIT["hidden_size"], LLM_HIDDEN, use_pixelshuffle=True)
-    return enc.to(torch.bfloat16).eval(), bridge.to(torch.bfloat16).eval()
+    return enc.to(torch.bfloat16).eval().requires_grad_(False), bridge.to(torch.bfloat16).eval().requires_grad_(False)
 
 
 def build_model(dev):
@@ -72,7 +77,7 @@ def build_model(dev):
                 p.normal_(0, 0.02)
     torch.manual_seed(1)
     bridge = build_vl_bridge("mlp2x_gelu", VIT["hidden_size"], LLM_HIDDEN, use_pixelshuffle=False)
-    return enc.to(dev).to(torch.bfloat16).eval(), bridge.to(dev).to(torch.bfloat16).eval()
+    return enc.to(dev).to(torch.bfloat16).eval().requires_grad_(False), bridge.to(dev).to(torch.bfloat16).eval().requires_grad_(False)
 
 
 def build_msda_inputs(dev, B, seed):
@@ -109,49 +114,61 @@ def event_time(fn, iters, stream=None):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
-    """Per-kernel achieved vs peak for the three kernels the north star names, each launched alone."""
+def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10):
+    """Achieved vs peak of every hot kernel of the workload, each launched alone (HIP events on torch's current stream =
+    the stream the C ABI launches on) + its launches per step.  cfg: VIT or IVIT; bridge_dims: [(M, N, K), ...]."""
     from visionllm_amd import _lib
     from visionllm_amd import ms_deform_attn as A
     L = _lib.lib()
     st = _lib.current_stream(torch.device(dev))
-    C, H, I = VIT["hidden_size"], VIT["num_attention_heads"], VIT["intermediate_size"]
-    S = (VIT["image_size"] // VIT["patch_size"]) ** 2 + 1
+    C, H, I, NL = cfg["hidden_size"], cfg["num_attention_heads"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    S = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
     D = C // H
     M = n_tiles * S
+    act = 2 if cfg["hidden_act"] == "quick_gelu" else 1
     out = {}
-    # (1) MSDA encoder-shaped call: HBM bound, algorithmic bytes = value + loc + attw + out (SURVEY 8d)
-    t = msda_in["enc"]
-    f = lambda: A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)  # noqa: E731
-    f(); torch.cuda.synchronize()
-    sec = event_time(f, iters)
-    ab = msda_bytes(t)
-    out["msda"] = dict(kernel="msda_fwd_tiled4_kernel<4 waves, 3 blocks per CU> (fp32, D32, encoder shape Lq=S=37485, B=8)", bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS,
-                       unit="GB/s", frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6,
-                       algorithmic_bytes=ab)
-    # (2) attention kernel: MFMA bound, flops = 4*H*S^2*d per tile
+    # MSDA: HBM bound, algorithmic bytes = value + loc + attw + out (SURVEY 8d)
+    for tag, nm, n_launch in (("enc", "msda", MSDA["enc_layers"]), ("dec", "msda_dec", MSDA["dec_layers"])):
+        t = msda_in[tag]
+        f = lambda: A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, iters)
+        ab = msda_bytes(t)
+        kern = ("msda_fwd_tiled7_kernel<12 waves, 1 block per CU> (fp32, D32, pyramid items, encoder shape Lq=S=37485, B=8)"
+                if tag == "enc" else "msda_fwd_vec_kernel (fp32, D32, decoder shape Lq=900, B=8)")
+        out[nm] = dict(kernel=kern, bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6, algorithmic_bytes=ab,
+                       launches_per_step=n_launch)
+    # attention: MFMA bound, flops = 4*H*S^2*d per tile
     qkv = torch.randn(n_tiles, S, 3, H, D, device=dev).to(torch.bfloat16)
     ao = torch.empty(n_tiles, S, H, D, dtype=torch.bfloat16, device=dev)
     f = lambda: _lib.check(L.vllm_attn_fwd_qkvpacked_bf16(_lib.ptr(qkv), _lib.ptr(ao), n_tiles, S, H, D, D ** -0.5, st))  # noqa: E731
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     fl = 4.0 * H * S * S * D * n_tiles
-    out["attn"] = dict(kernel="attn_fwd_kernel<D64> (ViT-L: 40 tiles x 16 heads x S577)", bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF,
-                       unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None, us_per_launch=sec * 1e6,
-                       algorithmic_flops=fl)
-    # (3) the dominant GEMM (MLP fc1: [M,1024] x [4096,1024]^T + bias + quick_gelu)
-    x = torch.randn(M, C, device=dev).to(torch.bfloat16)
-    w = (torch.randn(I, C, device=dev) * 0.02).to(torch.bfloat16)
-    b = torch.zeros(I, device=dev).to(torch.bfloat16)
-    y = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
-    f = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, I, C, C, C, I, 2,  # noqa: E731
-                                             None, None, 0, 0, st))
-    f(); torch.cuda.synchronize()
-    sec = event_time(f, iters)
-    fl = 2.0 * M * I * C
-    out["gemm"] = dict(kernel="gemm256_bf16_kernel<quick_gelu> (MLP fc1: M23080 N4096 K1024)", bound="mfma", achieved=fl / sec / 1e12,
+    out["attn"] = dict(kernel=f"attn_fwd_kernel<D{D}> ({n_tiles} tiles x {H} heads x S{S})", bound="mfma", achieved=fl / sec / 1e12,
                        peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None,
-                       us_per_launch=sec * 1e6, algorithmic_flops=fl)
+                       us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=NL)
+    del qkv, ao
+    # the four encoder GEMMs + the projector GEMMs
+    gemms = [("gemm_qkv", M, 3 * C, C, 0, NL), ("gemm_proj", M, C, C, 0, NL), ("gemm", M, I, C, act, NL), ("gemm_fc2", M, C, I, 0, NL)]
+    gemms += [(f"gemm_bridge{i}", m, n, k, 0, 1) for i, (m, n, k) in enumerate(bridge_dims)]
+    names = {"gemm": "MLP fc1", "gemm_qkv": "QKV", "gemm_proj": "attention out-proj (+LayerScale/residual in the step)",
+             "gemm_fc2": "MLP fc2 (+LayerScale/residual in the step)"}
+    for nm, m, n, k, epi, n_launch in gemms:
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.zeros(n, device=dev).to(torch.bfloat16)
+        y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        f = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, n, k, k, k, n, epi,  # noqa: E731
+                                                 None, None, 0, 0, st))
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, iters)
+        fl = 2.0 * m * n * k
+        out[nm] = dict(kernel=f"gemm256_bf16_kernel ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", bound="mfma",
+                       achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF,
+                       traffic=None, us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=n_launch)
+        del x, w, b, y
     # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -165,61 +182,97 @@ def kernel_rooflines(dev, enc, msda_in, n_tiles, iters=10):
     return out
 
 
-def cpu_baseline():
-    """The reference's CPU path (restated in oracle/), bounded sample, extrapolated to images/sec."""
+def _median_time(fn, reps=3, warmup=1):
+    """1 warm-up + >= 3 timed repetitions, median."""
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_baseline(ivit=False):
+    """The reference's CPU path on the host cores of this box, bounded sample, extrapolated to images/sec.
+
+    vitl: transformers.CLIPVisionModel (the class the reference instantiates, modeling_visionllmv2.py:135; eager attention,
+    fp32) on ONE 336^2 tile + the mlp2x_gelu bridge (oracle restatement of :174-182) + the reference's pure-torch MSDA
+    twin (oracle restatement of multi_scale_deform_attn.py:100-159, pinned to reference-run fixtures) at B=1 for the
+    encoder and decoder shapes.  internvit6b: the InternViT restatement (oracle/vit.py, pinned to the reference class's
+    fixtures) at 2 of 48 layers, one tile, extrapolated x24 (stated in `sample`)."""
     from msda_inputs import make_inputs
     from oracle import msda as OM
     from oracle import vit as OV
-    # host cores actually used: torch's CPU kernels stop scaling (and thrash) far below the 256 hardware threads of
-    # the GPU box for these single-tile problem sizes, so the baseline is given 32 threads (or all, if fewer).
+    # torch's CPU kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box for these
+    # single-tile problem sizes: 32 threads (or all, if fewer) is the fastest setting we measured
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    C, I, H = VIT["hidden_size"], VIT["intermediate_size"], VIT["num_attention_heads"]
-    S = (VIT["image_size"] // VIT["patch_size"]) ** 2 + 1
-    sd = {"embeddings.patch_embedding.weight": torch.randn(C, 3, 14, 14) * 0.02,
-          "embeddings.class_embedding": torch.randn(C) * 0.02,
-          "embeddings.position_embedding.weight": torch.randn(S, C) * 0.02,
-          "pre_layrnorm.weight": torch.ones(C), "pre_layrnorm.bias": torch.zeros(C)}
-    n_layers_sample = VIT["num_hidden_layers"]   # full depth for ONE tile (the sample is bounded by tile count)
-    for i in range(n_layers_sample):
-        p = f"encoder.layers.{i}."
-        for nm, shp in (("self_attn.q_proj", (C, C)), ("self_attn.k_proj", (C, C)), ("self_attn.v_proj", (C, C)),
-                        ("self_attn.out_proj", (C, C)), ("mlp.fc1", (I, C)), ("mlp.fc2", (C, I))):
-            sd[p + nm + ".weight"] = torch.randn(*shp) * 0.02
-            sd[p + nm + ".bias"] = torch.zeros(shp[0])
-        for nm in ("layer_norm1", "layer_norm2"):
-            sd[p + nm + ".weight"] = torch.ones(C)
-            sd[p + nm + ".bias"] = torch.zeros(C)
-    cfg = dict(VIT, num_hidden_layers=n_layers_sample)
-    x = torch.randn(1, 3, 336, 336)
     with torch.no_grad():
-        OV.clip_vit_forward(sd, dict(cfg, num_hidden_layers=1), x)  # warm-up
-        t0 = time.perf_counter()
-        hs = OV.clip_vit_forward(sd, cfg, x)
-        t_vit_sample = time.perf_counter() - t0
-        bsd = {"0.weight": torch.randn(LLM_HIDDEN, C) * 0.02, "0.bias": torch.zeros(LLM_HIDDEN),
-               "2.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "2.bias": torch.zeros(LLM_HIDDEN)}
-        t0 = time.perf_counter()
-        OV.bridge_forward(bsd, "mlp2x_gelu", hs[-2][:, 1:])
-        t_bridge = time.perf_counter() - t0
+        if not ivit:
+            from transformers import CLIPVisionConfig, CLIPVisionModel
+            model = CLIPVisionModel(CLIPVisionConfig(**VIT, attn_implementation="eager")).eval()
+            x = torch.randn(1, 3, 336, 336)
+            hs = [None]
+
+            def run_vit():
+                hs[0] = model(pixel_values=x, output_hidden_states=True).hidden_states
+            t_vit = _median_time(run_vit)
+            C = VIT["hidden_size"]
+            bsd = {"0.weight": torch.randn(LLM_HIDDEN, C) * 0.02, "0.bias": torch.zeros(LLM_HIDDEN),
+                   "2.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "2.bias": torch.zeros(LLM_HIDDEN)}
+            t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "mlp2x_gelu", hs[0][-2][:, 1:]))
+            vit_note = (f"transformers {__import__('transformers').__version__} CLIPVisionModel ViT-L/14-336 fp32 eager, 1 tile x 24 "
+                        f"layers ({t_vit:.2f}s) + mlp2x_gelu bridge 1 tile ({t_bridge:.2f}s)")
+        else:
+            cfg = dict(IVIT, num_hidden_layers=2)
+            C, I = IVIT["hidden_size"], IVIT["intermediate_size"]
+            S = (IVIT["image_size"] // IVIT["patch_size"]) ** 2 + 1
+            sd = {"embeddings.patch_embedding.weight": torch.randn(C, 3, 14, 14) * 0.02, "embeddings.patch_embedding.bias": torch.zeros(C),
+                  "embeddings.class_embedding": torch.randn(1, 1, C) * 0.02, "embeddings.position_embedding": torch.randn(1, S, C) * 0.02}
+            for i in range(2):
+                pfx = f"encoder.layers.{i}."
+                sd.update({pfx + "attn.qkv.weight": torch.randn(3 * C, C) * 0.02, pfx + "attn.q_norm.weight": torch.ones(C),
+                           pfx + "attn.k_norm.weight": torch.ones(C), pfx + "attn.proj.weight": torch.randn(C, C) * 0.02,
+                           pfx + "attn.proj.bias": torch.zeros(C), pfx + "mlp.fc1.weight": torch.randn(I, C) * 0.02,
+                           pfx + "mlp.fc1.bias": torch.zeros(I), pfx + "mlp.fc2.weight": torch.randn(C, I) * 0.02,
+                           pfx + "mlp.fc2.bias": torch.zeros(C), pfx + "norm1.weight": torch.ones(C), pfx + "norm2.weight": torch.ones(C),
+                           pfx + "ls1": torch.full((C,), 0.1), pfx + "ls2": torch.full((C,), 0.1)})
+            x = torch.randn(1, 3, 448, 448)
+            t2 = _median_time(lambda: OV.intern_vit_forward(sd, cfg, x))
+            t_vit = t2 * (IVIT["num_hidden_layers"] / 2)
+            bsd = {"0.weight": torch.ones(4 * C), "0.bias": torch.zeros(4 * C), "1.weight": torch.randn(LLM_HIDDEN, 4 * C) * 0.02,
+                   "1.bias": torch.zeros(LLM_HIDDEN), "3.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "3.bias": torch.zeros(LLM_HIDDEN)}
+            feats = OV.select_features([torch.randn(1, S, C)] * 2, -2, True)
+            t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "internvl_mlp", feats))
+            vit_note = (f"InternViT-6B restatement (oracle/vit.py) fp32, 1 tile of 448^2 x 2 of 48 layers ({t2:.2f}s), EXTRAPOLATED x24 = "
+                        f"{t_vit:.1f}s + pixel-shuffle + internvl_mlp bridge 1 tile ({t_bridge:.2f}s)")
         g = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], mode="encoder_like", seed=0)
         tv, tl, tw = torch.from_numpy(g["value"]), torch.from_numpy(g["loc"]), torch.from_numpy(g["attw"])
-        t0 = time.perf_counter()
-        OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw)
-        t_msda_enc = time.perf_counter() - t0
+        t_msda_enc = _median_time(lambda: OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw))
         gd = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], Lq=MSDA["dec_queries"], mode="encoder_like", seed=1)
-        t0 = time.perf_counter()
-        OM.grid_sample_twin(torch.from_numpy(gd["value"]), gd["shapes"].tolist(), torch.from_numpy(gd["loc"]),
-                            torch.from_numpy(gd["attw"]))
-        t_msda_dec = time.perf_counter() - t0
-    t_tile = t_vit_sample * (VIT["num_hidden_layers"] / n_layers_sample) + t_bridge
-    t_image = TILES_PER_IMAGE * t_tile + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
+        dv, dl, dw = torch.from_numpy(gd["value"]), torch.from_numpy(gd["loc"]), torch.from_numpy(gd["attw"])
+        t_msda_dec = _median_time(lambda: OM.grid_sample_twin(dv, gd["shapes"].tolist(), dl, dw))
+    t_image = TILES_PER_IMAGE * (t_vit + t_bridge) + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
     return dict(value=1.0 / t_image, unit="images/sec", cores=threads, kind="port",
-                sample=(f"torch fp32 oracle on {threads} threads: ViT-L/14-336 1 tile x {n_layers_sample}/24 layers "
-                        f"({t_vit_sample:.2f}s) + mlp2x_gelu bridge 1 tile "
-                        f"({t_bridge:.2f}s) + reference grid_sample MSDA twin B=1 Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 "
-                        f"({t_msda_dec:.2f}s); image = 5 tiles + 6 enc + 6 dec MSDA calls (B=1 each), extrapolated from this one-tile / one-call sample"))
+                sample=(f"{threads} host threads, 1 warm-up + 3 repetitions each, median: {vit_note} + reference grid_sample MSDA twin B=1 "
+                        f"Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 ({t_msda_dec:.2f}s); image = 5 tiles + 6 enc + 6 dec MSDA calls "
+                        f"(B=1 each; B=8 calls are 8x these), extrapolated from this one-tile / one-call sample"))
+
+
+def _respawn_under_launcher(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
@@ -231,17 +284,22 @@ def main():
     ap.add_argument("--workload", default="vitl", choices=["vitl", "internvit6b"],
                     help="vitl (default; the metric's ViT-L config) or internvit6b (BASELINE configs[2]: 5 tiles of 448^2 per "
                          "image through InternViT-6B + pixel-shuffle + internvl_mlp projector)")
-    ap.add_argument("--msda-stream", type=int, default=1, choices=[0, 1],
-                    help="1 (default): the MSDA kernels run on a side stream next to the ViT; 0: everything on one stream")
+    ap.add_argument("--msda-stream", type=int, default=0, choices=[0, 1],
+                    help="0 (default): one stream; 1: the MSDA calls on a side stream next to the ViT (cross-batch pipelining: in "
+                         "the reference the det head of a batch depends on that batch's LLM output)")
+    ap.add_argument("--allgather", default="collective", choices=["collective", "direct"],
+                    help="token all-gather: RCCL all_gather_into_tensor (default) or batched point-to-point to all peers at once")
     ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="0 / 1 (default): one launch sequence; k: the tiles as k chunks on k streams (measured slower)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_launcher(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
@@ -265,9 +323,6 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     pixels = torch.randn(n_tiles, 3, img, img, device=dev, generator=gen).to(torch.bfloat16)
     msda_in = build_msda_inputs(dev, IMAGES_PER_RANK, 200 + rank)
-
-    # The det-head MSDA kernels depend on backbone features, not on the ViT tokens of the same batch: they run on a side
-    # stream and fill the CUs the ViT GEMMs leave idle in their last round of tiles (proj / fc2: 364 tiles on 256 CUs).
     side = torch.cuda.Stream(device=dev) if args.msda_stream else None
 
     def msda_calls(res):
@@ -276,47 +331,76 @@ def main():
             for _ in range(n):
                 res.append(A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64))
 
-    def step():
+    def step(marks=None):
+        """marks: optional list receiving 4 HIP events (start, ViT+projector done, all-gather done, MSDA done); with marks the
+        collective is waited for before the MSDA calls so that the three phases can be told apart."""
         res = []
         main = torch.cuda.current_stream(dev)
+        ev = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())  # noqa: E731
+        if marks is not None:
+            ev()
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 msda_calls(res)
         out = enc(pixels, output_hidden_states=True)
         tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
+        if marks is not None:
+            ev()
         # the token all-gather (RCCL over xGMI, its own stream) overlaps the det-head MSDA kernels of this step
-        handle = all_gather_visual_tokens(tokens, counts=[tokens.shape[0]] * world, async_op=True)
+        handle = all_gather_visual_tokens(tokens, counts=[tokens.shape[0]] * world, async_op=True, algo=args.allgather)
+        if marks is not None:
+            gathered, _ = handle.wait()
+            ev()
         if side is None:
             msda_calls(res)
-        gathered, _ = handle.wait()
+        if marks is None:
+            gathered, _ = handle.wait()
         if side is not None:
             main.wait_stream(side)
+        if marks is not None:
+            ev()
         res.append(gathered)
         return res
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # per-phase times (outside the timed region): 3 instrumented steps, median per rank, max over ranks
+        ph = []
+        for _ in range(3):
+            marks = []
+            step(marks)
+            torch.cuda.synchronize()
+            ph.append([marks[i].elapsed_time(marks[i + 1]) for i in range(3)])
+        ph = np.median(np.array(ph), axis=0)
+    red = torch.tensor([dt, ph[0], ph[1], ph[2]], device=dev, dtype=torch.float64)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    dt = float(red[0].item())
 
     if rank == 0:
-        rl = kernel_rooflines(dev, enc, msda_in, IMAGES_PER_RANK * TILES_PER_IMAGE)
-        # dominant kernel by time share of a step: the GEMM family (~85 % of the ViT FLOPs)
+        cfg = IVIT if ivit else VIT
+        T = (cfg["image_size"] // cfg["patch_size"]) ** 2
+        bdims = ([(n_tiles * T // 4, LLM_HIDDEN, 4 * cfg["hidden_size"]), (n_tiles * T // 4, LLM_HIDDEN, LLM_HIDDEN)] if ivit else
+                 [(n_tiles * T, LLM_HIDDEN, cfg["hidden_size"]), (n_tiles * T, LLM_HIDDEN, LLM_HIDDEN)])
+        rl = kernel_rooflines(dev, msda_in, n_tiles, cfg, bdims)
+        step_us = dt / args.steps * 1e6
+        for v in rl.values():
+            v["share_of_step"] = v["launches_per_step"] * v["us_per_launch"] / step_us
+        dom = max(rl, key=lambda k: rl[k]["share_of_step"])
         line = {
             "metric": "images/sec (ViT-L+projector+MSDeformAttn fwd, 1336px)",
             "value": world * IMAGES_PER_RANK * args.steps / dt,
@@ -334,14 +418,20 @@ def main():
                                     "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4"), "images_per_gpu": IMAGES_PER_RANK,
                        "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336",
                        "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
-                       "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096", "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
+                       "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096",
+                       "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
                        "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else ""),
-                       "streams": ("vit+projector | msda (side stream)" if args.msda_stream else "single") + ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
-            "roofline": {k: rl["gemm"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": rl["gemm"]["kernel"]},
+                       "rccl_ranks": world, "allgather": args.allgather,
+                       "streams": ("vit+projector | msda (side stream; cross-batch pipelining)" if args.msda_stream else "single") +
+                                  ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
+            "phases_ms": {"vit_projector": float(red[1].item()), "token_allgather": float(red[2].item()), "msda_12_calls": float(red[3].item()),
+                          "note": "3 instrumented steps after the timed region (collective waited for before the MSDA calls), median per rank, max over ranks"},
+            "roofline": {k: rl[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} |
+                        {"kernel": rl[dom]["kernel"], "share_of_step": rl[dom]["share_of_step"]},
             "rooflines": rl,
         }
-        if world == 1 and not args.no_cpu_baseline and not ivit:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ivit)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

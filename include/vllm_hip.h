@@ -4,8 +4,9 @@
  * Plain pointers and sizes only (no torch / ATen types).  Every pointer marked "device" is a HIP device
  * pointer owned by the caller (PyTorch's caching allocator in practice); the library never allocates or
  * frees device memory and never synchronises: all work is enqueued on `stream` (a hipStream_t passed as
- * void*; NULL = the legacy default stream).  Thread-safety: entry points are re-entrant; the only global
- * state is the per-thread last-error string.
+ * void*; NULL = the legacy default stream).  Thread-safety: entry points are re-entrant.  Global state: the per-thread
+ * last-error string, and the PROCESS-WIDE tuning knobs of vllm_set_option() (plain ints read at launch time: change them
+ * only while no other thread is launching) plus one-time per-process caches (device CU count, kernel attributes).
  *
  * Return value: 0 on success, negative VLLM_E* on error (vllm_last_error() gives the message).  The Python
  * mirror (visionllm_amd/_lib.py) turns non-zero into RuntimeError, as the reference's C++ exceptions do
@@ -35,21 +36,24 @@ int vllm_abi_version(void);
 const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
-/* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped MSDA forward kernel (same results to fp32 rounding):
- * 0 plain gather kernel, 1 LDS-tiled kernel generation 4 with 4 waves per block, 360-pixel windows, 3 blocks per CU (default),
- * 8 the same with 560-pixel windows and 2 blocks per CU, 2 with 8 waves per block,
- * 3 LDS-tiled kernel generation 2, 4 generation 3 (software-pipelined), 5 generation 4 with the phase clock
- * (vllm_debug_counters), 6 / 7 generation 5 (producer / consumer waves, two windows, one block per CU) with 4 / 8 producer waves.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase kernel, 3 256x256 4-wave kernel,
- * 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the
- * 8-phase kernel's epilogue goes 0 through LDS (row-contiguous 16-byte stores), 1 straight from the accumulator layout,
- * 2 automatic (default; same results either way).  "attn_variant": bit0
- * software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted transpose reads, bit4 do
- * not trim padding keys / padding query waves, bit6 (head_dim 64) two 32-row query groups per wave (measured slower, opt-in), 32 automatic (default; currently 2).  Environment variables
- * VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the previous value or
- * VLLM_EINVAL for an unknown name. */
+/* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped (Lq == S) MSDA forward kernel, same results to fp32
+ * rounding: 0 plain gather kernel; 1 automatic (default): generation 7 (msda_tiled7.hip: pyramid items, software pipeline
+ * across items) when the level maps form an exact 2x pyramid -- decided on the device, no host sync -- else generation 4;
+ * 2 generation 4 with 8 waves per block; 3 generation 2; 5 generation 4 with the phase clock (vllm_debug_counters);
+ * 8 generation 4, 560-pixel windows, 2 blocks per CU; 9 generation 4, 360 pixels, 3 blocks per CU (the round-1 default);
+ * 10-14 generation 6 (msda_tiled6.hip; 10 / 14 with phase clock, 11-13 gather / staging variants); 15 generation 7;
+ * 16 generation 7 with the phase clock; 17 generation 6.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
+ * kernel, 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the 8-phase kernel's epilogue goes 0 through LDS
+ * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).
+ * "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted
+ * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).
+ * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
+ * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
+ * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */
 int vllm_set_option(const char *name, int value);
-/* Diagnostics: with "msda_tiled" = 5 the LDS-tiled MSDA kernel adds per-phase shader-clock ticks (wave 0 of every block) to
- * 16 device counters; this reads them into out[0..n) and clears them.  Returns the number of counters written. */
+/* Diagnostics: with "msda_tiled" = 5 / 10 / 14 / 16 the LDS-tiled MSDA kernel of that generation adds per-phase
+ * shader-clock ticks to 16 device counters; this reads the current generation's into out[0..n) and clears them.  Returns the
+ * number of counters written. */
 int vllm_debug_counters(long *out, int n);
 
 /* ------------------------------------------------------------------------------------------------

@@ -95,6 +95,180 @@ def gen_msda():
     case("odd_channels", 1, 3, 5, 19, [(5, 6), (3, 3)], 2, 13, "stress")
 
 
+def ast_extract_class(path, name, glb):
+    """exec ONE class definition of a reference file (decorators of the class and of its methods dropped)."""
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == name:
+            node.decorator_list = []
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef):
+                    sub.decorator_list = [d for d in sub.decorator_list
+                                          if isinstance(d, ast.Name) and d.id in ("staticmethod", "classmethod", "property")]
+            mod = ast.Module(body=[node], type_ignores=[])
+            ast.fix_missing_locations(mod)
+            exec(compile(mod, path, "exec"), glb)
+            return glb[name]
+    raise KeyError(name)
+
+
+def gen_msda_layer():
+    """The deformable-attention LAYER, run from the reference's own module classes on CPU (fp32 and fp64):
+
+      * UniPose ``MSDeformAttn`` (visionllmv2/model/unipose/ops/modules/ms_deform_attn.py:33-145), imported from its file
+        with a stub ``MultiScaleDeformableAttention`` extension module whose forward is the reference's own
+        ``ms_deform_attn_core_pytorch`` (unipose/ops/functions/ms_deform_attn_func.py:41-61): 2-d reference points,
+        4-d reference points, 4-d with ``use_4D_normalizer``;
+      * mmcv ``MultiScaleDeformableAttention`` (mmcv/mmcv/ops/multi_scale_deform_attn.py:162-367), AST-extracted class
+        (``import mmcv`` needs the compiled ``_ext``); on CPU tensors its forward takes its own torch path (:353-359);
+      * ``GroundingDinoMultiscaleDeformableAttention`` (visionllmv2/model/grounding_dino/
+        modeling_ov_grounding_dino_mask_dn.py:645-784), AST-extracted class, ``disable_custom_kernels=True``.
+    Inputs, parameters and outputs are recorded; tests pin oracle.msda.layer_forward and the three module mirrors."""
+    import math
+    import warnings
+    from typing import Optional
+    from torch import Tensor
+
+    # ---- UniPose module, imported from its file under a stub package ----
+    func_path = f"{REF}/visionllmv2/model/unipose/ops/functions/ms_deform_attn_func.py"
+    mod_path = f"{REF}/visionllmv2/model/unipose/ops/modules/ms_deform_attn.py"
+    ext = types.ModuleType("MultiScaleDeformableAttention")
+    sys.modules["MultiScaleDeformableAttention"] = ext
+    for pkg in ("refops", "refops.functions", "refops.modules"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    spec = importlib.util.spec_from_file_location("refops.functions.ms_deform_attn_func", func_path)
+    fmod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = fmod
+    spec.loader.exec_module(fmod)
+    ext.ms_deform_attn_forward = lambda value, shapes, lsi, loc, w, step: fmod.ms_deform_attn_core_pytorch(value, shapes, loc, w)
+    sys.modules["refops.functions"].MSDeformAttnFunction = fmod.MSDeformAttnFunction
+    spec = importlib.util.spec_from_file_location("refops.modules.ms_deform_attn", mod_path)
+    mmod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mmod
+    spec.loader.exec_module(mmod)
+    RefMSDeformAttn = mmod.MSDeformAttn
+
+    # ---- mmcv module (AST) ----
+    class BaseModule(nn.Module):            # mmcv.runner.BaseModule: only the init_cfg argument is used here
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    glb = {"torch": torch, "nn": nn, "F": F, "math": math, "warnings": warnings, "Optional": Optional,
+           "BaseModule": BaseModule, "mmcv": types.SimpleNamespace(ConfigDict=dict)}
+
+    def xavier_init(module, gain=1, bias=0, distribution="normal"):
+        (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+        if module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def constant_init(module, val, bias=0):
+        nn.init.constant_(module.weight, val)
+        if module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    glb.update(xavier_init=xavier_init, constant_init=constant_init)
+    mm_path = f"{REF}/mmcv/mmcv/ops/multi_scale_deform_attn.py"
+    glb.update(ast_extract(mm_path, ["multi_scale_deformable_attn_pytorch"], glb))
+    RefMMCV = ast_extract_class(mm_path, "MultiScaleDeformableAttention", glb)
+
+    # ---- Grounding-DINO module (AST) ----
+    gd_path = f"{REF}/visionllmv2/model/grounding_dino/modeling_ov_grounding_dino_mask_dn.py"
+    glb2 = {"torch": torch, "nn": nn, "F": F, "math": math, "warnings": warnings, "Optional": Optional, "Tensor": Tensor,
+            "GroundingDinoConfig": object}
+    glb2.update(ast_extract(gd_path, ["multi_scale_deformable_attention"], glb2))
+    RefGD = ast_extract_class(gd_path, "GroundingDinoMultiscaleDeformableAttention", glb2)
+
+    shapes = [(9, 7), (5, 4), (3, 2)]
+    L, M, P, C, B, Lq = 3, 4, 4, 64, 2, 23
+    S = sum(h * w for h, w in shapes)
+    ss = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+
+    def randomise(mod, names, seed):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for n in names:
+                lin = getattr(mod, n)
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * (0.5 if "attention" in n else 0.08))
+                lin.bias.add_(torch.randn(lin.bias.shape, generator=g) * 0.05)
+
+    def inputs(seed, ref_dim):
+        g = torch.Generator().manual_seed(seed)
+        query = torch.randn(B, Lq, C, generator=g)
+        src = torch.randn(B, S, C, generator=g)
+        ref = torch.rand(B, Lq, L, ref_dim, generator=g)
+        if ref_dim == 4:
+            ref[..., 2:] = ref[..., 2:] * 0.4 + 0.05
+        mask = torch.zeros(B, S, dtype=torch.bool)
+        mask[1, -9:] = True
+        mask[0, 3:6] = True
+        return query, src, ref, mask
+
+    out = {"shapes": ss.numpy(), "lsi": lsi.numpy(), "n_heads": np.array(M), "n_levels": np.array(L), "n_points": np.array(P),
+           "torch_version": np.array(torch.__version__)}
+    names = ["sampling_offsets", "attention_weights", "value_proj", "output_proj"]
+    for tag, ref_dim, use4d in (("ref2", 2, False), ("ref4", 4, False), ("ref4_norm", 4, True)):
+        torch.manual_seed(0)
+        mod = RefMSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=P, use_4D_normalizer=use4d).eval()
+        randomise(mod, names, 5)
+        query, src, ref, mask = inputs(7 + ref_dim + use4d, ref_dim)
+        with torch.no_grad():
+            y32 = mod(query, ref, src, ss, lsi, mask)
+            y64 = mod.double()(query.double(), ref.double(), src.double(), ss, lsi, mask)
+        for k, v in mod.float().state_dict().items():
+            out[f"unipose_{tag}.sd.{k}"] = v.numpy()
+        out.update({f"unipose_{tag}.query": query.numpy(), f"unipose_{tag}.src": src.numpy(), f"unipose_{tag}.ref": ref.numpy(),
+                    f"unipose_{tag}.mask": mask.numpy(), f"unipose_{tag}.out_f32": y32.numpy(), f"unipose_{tag}.out_f64": y64.numpy(),
+                    f"unipose_{tag}.use4d": np.array(use4d)})
+        print(f"msda_layer unipose_{tag}: out {tuple(y32.shape)} |f32-f64| {(y32.double() - y64).abs().max():.2e}")
+
+    # mmcv: (num_query, bs, C) layout (batch_first=False), identity residual, dropout in eval mode = identity, query_pos
+    for tag, ref_dim in (("ref2", 2), ("ref4", 4)):
+        torch.manual_seed(0)
+        mod = RefMMCV(embed_dims=C, num_heads=M, num_levels=L, num_points=P, dropout=0.1).eval()
+        randomise(mod, names, 6)
+        query, src, ref, mask = inputs(17 + ref_dim, ref_dim)
+        g = torch.Generator().manual_seed(3)
+        qpos = torch.randn(B, Lq, C, generator=g) * 0.1
+        with torch.no_grad():
+            y32 = mod(query.transpose(0, 1), value=src.transpose(0, 1), query_pos=qpos.transpose(0, 1), key_padding_mask=mask,
+                      reference_points=ref, spatial_shapes=ss, level_start_index=lsi)
+            y64 = mod.double()(query.double().transpose(0, 1), value=src.double().transpose(0, 1),
+                               query_pos=qpos.double().transpose(0, 1), key_padding_mask=mask, reference_points=ref.double(),
+                               spatial_shapes=ss, level_start_index=lsi)
+        for k, v in mod.float().state_dict().items():
+            out[f"mmcv_{tag}.sd.{k}"] = v.numpy()
+        out.update({f"mmcv_{tag}.query": query.numpy(), f"mmcv_{tag}.src": src.numpy(), f"mmcv_{tag}.ref": ref.numpy(),
+                    f"mmcv_{tag}.mask": mask.numpy(), f"mmcv_{tag}.query_pos": qpos.numpy(),
+                    f"mmcv_{tag}.out_f32": y32.numpy(), f"mmcv_{tag}.out_f64": y64.numpy()})
+        print(f"msda_layer mmcv_{tag}: out {tuple(y32.shape)} (num_query, bs, C)")
+
+    # Grounding-DINO: attention_mask is the INVERSE of a padding mask (:733-735), position embeddings added to the query
+    for tag, ref_dim in (("ref2", 2), ("ref4", 4)):
+        cfg = types.SimpleNamespace(d_model=C, num_feature_levels=L, disable_custom_kernels=True)
+        torch.manual_seed(0)
+        mod = RefGD(cfg, num_heads=M, n_points=P).eval()
+        randomise(mod, names, 8)
+        query, src, ref, mask = inputs(27 + ref_dim, ref_dim)
+        g = torch.Generator().manual_seed(4)
+        pos = torch.randn(B, Lq, C, generator=g) * 0.1
+        with torch.no_grad():
+            y32, aw32 = mod(query, attention_mask=~mask, encoder_hidden_states=src, position_embeddings=pos, reference_points=ref,
+                            spatial_shapes=ss, level_start_index=lsi)
+            y64, _ = mod.double()(query.double(), attention_mask=~mask, encoder_hidden_states=src.double(),
+                                  position_embeddings=pos.double(), reference_points=ref.double(), spatial_shapes=ss,
+                                  level_start_index=lsi)
+        for k, v in mod.float().state_dict().items():
+            out[f"gdino_{tag}.sd.{k}"] = v.numpy()
+        out.update({f"gdino_{tag}.query": query.numpy(), f"gdino_{tag}.src": src.numpy(), f"gdino_{tag}.ref": ref.numpy(),
+                    f"gdino_{tag}.mask": mask.numpy(), f"gdino_{tag}.pos": pos.numpy(), f"gdino_{tag}.out_f32": y32.numpy(),
+                    f"gdino_{tag}.out_f64": y64.numpy(), f"gdino_{tag}.attw_f32": aw32.numpy()})
+        print(f"msda_layer gdino_{tag}: out {tuple(y32.shape)}")
+    np.savez_compressed(os.path.join(OUT, "msda_layer.npz"), **out)
+
+
 def gen_dcnv3():
     """DCNv3 forward: the reference's pure-PyTorch twin on the inputs of its own test (ops_dcnv3/test.py:19-66, seed 3:
     N=2, 8x8, M=4, D=16, 3x3, offset_scale 2, pad 1) plus strided / dilated / non-square cases."""
@@ -301,6 +475,7 @@ def gen_tiling():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_msda()
+    gen_msda_layer()
     gen_dcnv3()
     gen_point_sample()
     gen_intern_vit()

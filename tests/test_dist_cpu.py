@@ -38,6 +38,10 @@ def _worker(rank, world, port, ragged, q):
     h = all_gather_visual_tokens(tok, counts=counts, async_op=True)
     out2, counts2 = h.wait()
     assert counts2 == counts and torch.equal(out2, out)
+    # the direct (all peers at once, batched point-to-point) algorithm gives the same tensor, blocking and asynchronous
+    out3, counts3 = all_gather_visual_tokens(tok, algo="direct")
+    out4, _ = all_gather_visual_tokens(tok, counts=counts, async_op=True, algo="direct").wait()
+    assert counts3 == counts and torch.equal(out3, out) and torch.equal(out4, out)
     q.put((rank, out.float(), counts))
     dist.destroy_process_group()
 

@@ -355,6 +355,121 @@ def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M):
         _lib.set_option("msda_tiled", old)
 
 
+# ---- the three module mirrors vs the reference's OWN module classes (fixtures: oracle/gen_golden.py::gen_msda_layer) ----
+def _load_layer(g, prefix, mod):
+    sd = {k[len(prefix) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix + ".sd.")}
+    mod.load_state_dict(sd, strict=True)
+    return mod.to(DEV).eval()
+
+
+def _bf16_close(out, ref, what):
+    """bf16 modules: parameters and activations are rounded to bf16 (8 significand bits) at four linears; the fp32
+    reference on the UNROUNDED parameters is matched to a few bf16 ulp of the output scale."""
+    err = (out.float().cpu() - torch.from_numpy(ref).float()).abs()
+    scale = float(np.abs(ref).max())
+    assert err.max().item() <= 4e-2 * scale and err.mean().item() <= 6e-3 * scale, (what, err.max().item(), err.mean().item(), scale)
+
+
+@pytest.mark.parametrize("tag", ["unipose_ref2", "unipose_ref4", "unipose_ref4_norm"])
+def test_unipose_module_vs_reference_module(tag):
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    C = g[f"{tag}.query"].shape[-1]
+    mod = _load_layer(g, tag, A.MSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=P, use_4D_normalizer=bool(g[f"{tag}.use4d"])))
+    args = (_t(g[f"{tag}.query"]), _t(g[f"{tag}.ref"]), _t(g[f"{tag}.src"]), _t(g["shapes"]), _t(g["lsi"]), _t(g[f"{tag}.mask"]))
+    with torch.no_grad():
+        out = mod(*args)                                        # fp32: torch linears around the native operator
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
+        mb = mod.to(torch.bfloat16)                             # bf16: the fused native layer (one C call)
+        ob = mb(args[0].bfloat16(), args[1], args[2].bfloat16(), *args[3:])
+    assert ob.dtype == torch.bfloat16
+    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+
+
+@pytest.mark.parametrize("tag", ["mmcv_ref2", "mmcv_ref4"])
+def test_mmcv_module_vs_reference_module(tag):
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    C = g[f"{tag}.query"].shape[-1]
+    mod = _load_layer(g, tag, A.MultiScaleDeformableAttention(embed_dims=C, num_heads=M, num_levels=L, num_points=P, dropout=0.1))
+    q, src, pos = (_t(g[f"{tag}.{n}"]).transpose(0, 1) for n in ("query", "src", "query_pos"))
+    kw = dict(key_padding_mask=_t(g[f"{tag}.mask"]), reference_points=_t(g[f"{tag}.ref"]), spatial_shapes=_t(g["shapes"]),
+              level_start_index=_t(g["lsi"]))
+    with torch.no_grad():
+        out = mod(q, value=src, query_pos=pos, **kw)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
+        ob = mod.to(torch.bfloat16)(q.bfloat16(), value=src.bfloat16(), query_pos=pos.bfloat16(), **kw)
+    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+
+
+@pytest.mark.parametrize("tag", ["gdino_ref2", "gdino_ref4"])
+def test_grounding_dino_module_vs_reference_module(tag):
+    import types
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    C = g[f"{tag}.query"].shape[-1]
+    cfg = types.SimpleNamespace(d_model=C, num_feature_levels=L, disable_custom_kernels=False)
+    mod = _load_layer(g, tag, A.GroundingDinoMultiscaleDeformableAttention(cfg, num_heads=M, n_points=P))
+    kw = dict(attention_mask=~_t(g[f"{tag}.mask"]), reference_points=_t(g[f"{tag}.ref"]), spatial_shapes=_t(g["shapes"]),
+              level_start_index=_t(g["lsi"]))
+    with torch.no_grad():
+        out, aw = mod(_t(g[f"{tag}.query"]), encoder_hidden_states=_t(g[f"{tag}.src"]), position_embeddings=_t(g[f"{tag}.pos"]), **kw)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(aw.cpu().numpy(), g[f"{tag}.attw_f32"], rtol=2e-5, atol=2e-6)
+        ob, _ = mod.to(torch.bfloat16)(_t(g[f"{tag}.query"]).bfloat16(), encoder_hidden_states=_t(g[f"{tag}.src"]).bfloat16(),
+                                       position_embeddings=_t(g[f"{tag}.pos"]).bfloat16(), **kw)
+    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+
+
+def test_compat_shims_module_name_and_mmcv_ext():
+    """B3: ``import MultiScaleDeformableAttention as MSDA`` (unipose/ops/functions/ms_deform_attn_func.py:18; list-returning
+    backward, ms_deform_attn.h:41-61) and the ``mmcv._ext`` alias (in-place backward, mmcv csrc ms_deform_attn.cpp:48-60),
+    called the way the reference's autograd Functions call them."""
+    import importlib
+    import os
+    import sys
+    import types
+    import visionllm_amd
+    compat = os.path.join(os.path.dirname(visionllm_amd.__file__), "compat")
+    g = load_golden("msda_stress_d32.npz")
+    t = [_t(g[k]) for k in ("value", "shapes", "lsi", "loc", "attw")]
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
+    go = torch.randn(ref.shape, device=DEV)
+    rv, rl, rw = O.backward(g["value"].astype(np.float64), g["shapes"], g["lsi"], g["loc"].astype(np.float64),
+                            g["attw"].astype(np.float64), go.cpu().numpy().astype(np.float64))
+    sys.path.insert(0, compat)
+    try:
+        MSDA = importlib.import_module("MultiScaleDeformableAttention")
+        out = MSDA.ms_deform_attn_forward(*t, 64)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+        gv, gl, gw = MSDA.ms_deform_attn_backward(*t, go, 64)
+        np.testing.assert_allclose(gw.cpu().numpy(), rw, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-3, atol=1e-3)
+    finally:
+        sys.path.remove(compat)
+        sys.modules.pop("MultiScaleDeformableAttention", None)
+    had = {k: sys.modules.get(k) for k in ("mmcv", "mmcv._ext")}
+    try:
+        sys.modules.setdefault("mmcv", types.ModuleType("mmcv"))
+        from visionllm_amd.compat import mmcv_ext
+        mmcv_ext.install(force=True)
+        ext = importlib.import_module("mmcv." + "_ext")           # == mmcv.utils.ext_loader.load_ext('_ext', [...])
+        for fun in ("ms_deform_attn_backward", "ms_deform_attn_forward"):
+            assert hasattr(ext, fun), f"{fun} miss in module _ext"
+        out = ext.ms_deform_attn_forward(*t, im2col_step=64)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+        gv, gl, gw = torch.zeros_like(t[0]), torch.zeros_like(t[3]), torch.zeros_like(t[4])
+        ext.ms_deform_attn_backward(*t, go.contiguous(), gv, gl, gw, im2col_step=64)
+        np.testing.assert_allclose(gw.cpu().numpy(), rw, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-3, atol=1e-3)
+    finally:
+        for k, v in had.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def test_modules_match_oracle_composition():
     """MSDeformAttn / mmcv module / GDINO module == (torch Linear layers + oracle op) on the same weights."""
     torch.manual_seed(0)

@@ -94,3 +94,44 @@ def test_empty_query_and_batch():
     out = O.forward(np.zeros((1, 6, 2, 4), np.float32), shapes, lsi, np.zeros((1, 0, 2, 1, 2, 2), np.float32),
                     np.zeros((1, 0, 2, 1, 2), np.float32))
     assert out.shape == (1, 0, 8)
+
+
+# ---- the deformable-attention LAYER: oracle.layer_forward vs the reference's own module classes (gen_golden.gen_msda_layer) ----
+def _layer_params(g, prefix):
+    return {n: (g[f"{prefix}.sd.{n}.weight"], g[f"{prefix}.sd.{n}.bias"])
+            for n in ("value_proj", "sampling_offsets", "attention_weights", "output_proj")}
+
+
+@pytest.mark.parametrize("tag", ["unipose_ref2", "unipose_ref4", "unipose_ref4_norm"])
+def test_layer_oracle_vs_reference_unipose_module(tag):
+    """MSDeformAttn.forward (unipose/ops/modules/ms_deform_attn.py:83-145): 2-d / 4-d reference points, use_4D_normalizer."""
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    out, _, _ = O.layer_forward(g[f"{tag}.query"], g[f"{tag}.ref"], g[f"{tag}.src"], g["shapes"], g["lsi"], g[f"{tag}.mask"],
+                                _layer_params(g, tag), M, L, P, use_4d_normalizer=bool(g[f"{tag}.use4d"]))
+    # (the reference module runs its operator in fp32 whatever the module dtype -- "for mixed precision",
+    # ms_deform_attn.py:131-139 -- so its float64 output carries fp32 rounding of the sampling core)
+    np.testing.assert_allclose(out, g[f"{tag}.out_f64"], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["mmcv_ref2", "mmcv_ref4"])
+def test_layer_oracle_vs_reference_mmcv_module(tag):
+    """mmcv MultiScaleDeformableAttention.forward (multi_scale_deform_attn.py:262-367): query_pos added to the query,
+    (num_query, bs, C) layout, identity residual (dropout is the identity in eval mode)."""
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    q = g[f"{tag}.query"].astype(np.float64)
+    out, _, _ = O.layer_forward(q + g[f"{tag}.query_pos"], g[f"{tag}.ref"], g[f"{tag}.src"], g["shapes"], g["lsi"],
+                                g[f"{tag}.mask"], _layer_params(g, tag), M, L, P)
+    np.testing.assert_allclose((out + q).transpose(1, 0, 2), g[f"{tag}.out_f64"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag", ["gdino_ref2", "gdino_ref4"])
+def test_layer_oracle_vs_reference_grounding_dino_module(tag):
+    """GroundingDinoMultiscaleDeformableAttention.forward (...mask_dn.py:706-784): position embeddings, inverted mask."""
+    g = load_golden("msda_layer.npz")
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    out, _, aw = O.layer_forward(g[f"{tag}.query"].astype(np.float64) + g[f"{tag}.pos"], g[f"{tag}.ref"], g[f"{tag}.src"],
+                                 g["shapes"], g["lsi"], g[f"{tag}.mask"], _layer_params(g, tag), M, L, P)
+    np.testing.assert_allclose(out, g[f"{tag}.out_f64"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(aw, g[f"{tag}.attw_f32"], rtol=2e-5, atol=2e-6)

@@ -389,7 +389,8 @@ def test_real_width_encoders_vs_oracle(arch):
     _check_states(out.hidden_states, ref, lo, arch)
 
 
-@pytest.mark.parametrize("kind,ps", [("linear", False), ("mlp2x_gelu", False), ("internvl_mlp", True), ("mlp2x_gelu", True)])
+@pytest.mark.parametrize("kind,ps", [("linear", False), ("mlp2x_gelu", False), ("internvl_mlp", True), ("mlp2x_gelu", True),
+                                     ("internvl_mlp", False)])   # (internvl_mlp without pixel-shuffle: modeling_visionllmv2.py:163-172)
 def test_bridge_vs_oracle(kind, ps):
     torch.manual_seed(3)
     n, hw, C, Cl = 3, 8, 128, 256
@@ -403,6 +404,9 @@ def test_bridge_vs_oracle(kind, ps):
     feats = V.select_features([hidden.float(), hidden.float()], -2, ps)
     ref = V.bridge_forward(sd, kind, feats)
     br = br.to(DEV).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):   # forward-only kernels: trainable parameters + grad mode must not silently lose the gradient
+        br.project_hidden_state(hidden.to(DEV), ps)
+    br.requires_grad_(False)
     out = br.project_hidden_state(hidden.to(DEV), ps)   # fused path: CLS skipped / shuffled in-kernel
     close(out, ref, 1.5e-2, f"bridge {kind} fused")
     out2 = br(feats.to(torch.bfloat16).to(DEV))          # drop-in path: the tensor the reference passes at :579
@@ -462,7 +466,7 @@ def test_cfg1_vitl14_336_full_depth_plus_bridge_vs_oracle():
     bsd = {k: bf(v.detach()).float() for k, v in br.state_dict().items()}
     x = torch.randn(1, 3, 336, 336)
     model = model.to(DEV).to(torch.bfloat16)
-    br = br.to(DEV).to(torch.bfloat16)
+    br = br.to(DEV).to(torch.bfloat16).requires_grad_(False)
     out = model(bf(x).to(DEV), output_hidden_states=True)
     tok = br.project_hidden_state(out.hidden_states[-2], False)
     fwd = lambda s, c, xx: V.clip_vit_forward(s, c, xx, prefix="vision_model.")  # noqa: E731

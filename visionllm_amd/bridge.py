@@ -79,6 +79,11 @@ class _BridgeMixin:
     def _native(self, x, pixel_shuffle_flag=False, skip_cls=False):
         if not x.is_cuda or x.dtype != torch.bfloat16:
             raise RuntimeError("vl_bridge: bf16 CUDA input required (no CPU path)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # the reference trains this slot (tune_vl_bridge); the native kernels are forward-only and their output has no
+            # grad_fn: refuse loudly instead of silently cutting the gradient
+            raise RuntimeError("vl_bridge (native): forward-only kernels -- call under torch.no_grad() or freeze the "
+                               "projector and its input (requires_grad_(False)); training the projector needs the torch modules")
         x = x.contiguous()
         n, rows, C = x.shape
         T = rows - 1 if skip_cls else rows

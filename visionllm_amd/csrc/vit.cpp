@@ -175,9 +175,17 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
     }
     if (d->kind == VLLM_BRIDGE_INTERNVL_MLP) {
         VLLM_REQUIRE(d->ln_w && d->ln_b, "bridge: internvl_mlp needs LayerNorm parameters");
-        VLLM_REQUIRE(xP == 0, "bridge: internvl_mlp without pixel_shuffle is not wired (LayerNorm reads contiguous rows)");
         uint16_t *ln = (uint16_t *)(ws + w.b);
-        TRY(norm_bf16_launch(false, x, ldx, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st));
+        if (xP == 0) {
+            TRY(norm_bf16_launch(false, x, ldx, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st));
+        } else {
+            // no pixel-shuffle (modeling_visionllmv2.py:163-172 allows it): the LayerNorm reads hidden[:, 1:] in place, one
+            // launch per tile (its rows are contiguous behind the tile's CLS row), and writes the rows densely
+            for (int t = 0; t < n; ++t)
+                TRY(norm_bf16_launch(false, hidden + ((long)t * S + 1) * C, C, d->ln_w, d->ln_b, ln + (long)t * T_in * Cin, Cin, T_in,
+                                     Cin, d->ln_eps, st));
+            xP = 0;
+        }
         x = ln; ldx = Cin;
     }
     uint16_t *tmp[2] = {(uint16_t *)(ws + w.c), (uint16_t *)(ws + w.c + align256(rows * (long)Cout * 2))};

@@ -50,9 +50,10 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
     out = torch.empty((N, Ho, Wo, C), dtype=input.dtype, device=input.device)
     L = _lib.lib()
     fn = L.vllm_dcnv3_forward_f32 if input.dtype == torch.float32 else L.vllm_dcnv3_forward_f64
-    _lib.check(fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), N, H, W, group, group_channels, kernel_h, kernel_w,
-                  stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, float(offset_scale), _lib.ptr(out),
-                  _lib.current_stream(input.device)), "vllm_dcnv3_forward")
+    with torch.cuda.device(input.device):
+        _lib.check(fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), N, H, W, group, group_channels, kernel_h, kernel_w,
+                      stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, float(offset_scale), _lib.ptr(out),
+                      _lib.current_stream(input.device)), "vllm_dcnv3_forward")
     return out
 
 

@@ -7,6 +7,7 @@ x 5 tiles) over RCCL/xGMI.  Tiles per rank vary (1-7 tiles per image), so the co
 payload is padded to the maximum (``all_gather_into_tensor`` needs equal shards).  On ROCm the ``nccl`` backend IS
 RCCL; ``gloo`` is used by the CPU tests.
 """
+import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -43,8 +44,43 @@ class GatherHandle:
         return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(len(counts))], 0), counts
 
 
-def all_gather_visual_tokens(tokens: torch.Tensor, group=None, counts: Sequence[int] = None, async_op: bool = False):
+class _Works:
+    """A set of point-to-point requests behaving like one collective work handle."""
+
+    def __init__(self, reqs):
+        self._reqs = reqs
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+
+
+def _direct_all_gather(out, shard, mx, group, async_op):
+    """All peers at once: every rank posts one send per peer and one receive per peer (batched point-to-point), the
+    pattern SURVEY.md section 5 argues for on the xGMI full mesh (7 links x ~153 GB/s per GPU, all busy at the same time,
+    84-189 MB per message) instead of a ring that is bound by one link.  RCCL runs the batch on its own stream."""
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    out[rank * mx:(rank + 1) * mx].copy_(shard)
+    ops = []
+    for step in range(1, ws):                       # staggered peers: rank r talks to r+step / r-step in round `step`
+        dst, src = (rank + step) % ws, (rank - step) % ws
+        ops.append(dist.P2POp(dist.isend, shard, dist.get_global_rank(group, dst) if group is not None else dst, group))
+        ops.append(dist.P2POp(dist.irecv, out[src * mx:(src + 1) * mx], dist.get_global_rank(group, src) if group is not None else src, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return _Works(reqs)
+    for r in reqs:
+        r.wait()
+    return None
+
+
+def all_gather_visual_tokens(tokens: torch.Tensor, group=None, counts: Sequence[int] = None, async_op: bool = False,
+                             algo: str = None):
     """tokens [n_tiles_r, T, C] -> ([sum_r n_tiles_r, T, C] in rank order, tiles per rank).
+
+    ``algo``: "collective" (default; RCCL's all_gather_into_tensor picks its own algorithm) or "direct" (batched
+    point-to-point to every peer at once, see _direct_all_gather); the environment variable VLLM_ALLGATHER overrides the
+    default.
 
     One small all-gather of the counts (skipped when the caller passes ``counts`` -- e.g. it sharded the images itself
     with ``shard_images`` -- which also avoids the host sync of reading them back), one large all-gather of the
@@ -70,6 +106,12 @@ def all_gather_visual_tokens(tokens: torch.Tensor, group=None, counts: Sequence[
         pad[: tokens.shape[0]] = tokens
         tokens = pad
     out = torch.empty((ws * mx, T, C), dtype=tokens.dtype, device=tokens.device)
-    work = dist.all_gather_into_tensor(out, tokens.contiguous(), group=group, async_op=async_op)
+    algo = algo or os.environ.get("VLLM_ALLGATHER", "collective")
+    if algo not in ("collective", "direct"):
+        raise ValueError(f"all_gather_visual_tokens: unknown algo {algo!r}")
+    if algo == "direct":
+        work = _direct_all_gather(out, tokens.contiguous(), mx, group, async_op)
+    else:
+        work = dist.all_gather_into_tensor(out, tokens.contiguous(), group=group, async_op=async_op)
     h = GatherHandle(work if async_op else None, out, counts_l, mx)
     return h if async_op else h.wait()

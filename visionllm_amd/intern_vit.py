@@ -152,15 +152,16 @@ class InternVisionModel(nn.Module):
 
     # -- reference API ------------------------------------------------------------------------------------
     def resize_pos_embeddings(self, old_size, new_size, patch_size):
-        """modeling_intern_vit.py:291-300 (bicubic, host-side one-off: plain torch)."""
+        """Same contract as modeling_intern_vit.py:291-300: the patch part of the position table is resampled bicubically
+        (align_corners=False, in fp32) from the (old_size / patch)^2 grid to the (new_size / patch)^2 grid; the CLS entry is
+        kept.  Host-side one-off, plain torch."""
         import torch.nn.functional as F
-        pos_emb = self.embeddings.position_embedding
-        _, _, embed_dim = pos_emb.shape
-        cls_emb = pos_emb[:, :1, :]
-        pos_emb = pos_emb[:, 1:, :].reshape(1, old_size // patch_size, old_size // patch_size, -1).permute(0, 3, 1, 2)
-        pos_emb = F.interpolate(pos_emb.float(), size=new_size // patch_size, mode="bicubic", align_corners=False)
-        pos_emb = pos_emb.to(cls_emb.dtype).reshape(1, embed_dim, -1).permute(0, 2, 1)
-        self.embeddings.position_embedding = nn.Parameter(torch.cat([cls_emb, pos_emb], dim=1))
+        table = self.embeddings.position_embedding                      # [1, 1 + g*g, C]
+        g_old, g_new, C = old_size // patch_size, new_size // patch_size, table.shape[-1]
+        grid = table[0, 1:].reshape(g_old, g_old, C).permute(2, 0, 1)[None].float()
+        grid = F.interpolate(grid, size=(g_new, g_new), mode="bicubic", align_corners=False)
+        patches = grid[0].permute(1, 2, 0).reshape(1, g_new * g_new, C).to(table.dtype)
+        self.embeddings.position_embedding = nn.Parameter(torch.cat([table[:, :1], patches], dim=1))
         self.embeddings.image_size = new_size
         self.config.image_size = new_size
 

@@ -230,12 +230,17 @@ def _sampling_locations(reference_points, sampling_offsets, spatial_shapes, n_po
         "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
 
 
-def msda_layer_fused_ok(query, input_flatten, *linears):
+def msda_layer_fused_ok(query, input_flatten, *linears, reference_points=None):
     """The fused HIP layer serves inference-dtype (bf16) modules on the GPU; anything else keeps the composed path."""
     if not (query.is_cuda and query.dtype == torch.bfloat16 and input_flatten.dtype == torch.bfloat16):
         return False
-    if torch.is_grad_enabled() and any(p.requires_grad for lin in linears for p in lin.parameters()):
-        return False   # training differentiates through the composed path (autograd Function around the operator)
+    if torch.is_grad_enabled():
+        # training differentiates through the composed path (autograd Function around the operator): trainable
+        # parameters, or a frozen module whose INPUTS carry gradients to upstream layers (the fused call has no grad_fn)
+        if any(p.requires_grad for lin in linears for p in lin.parameters()):
+            return False
+        if query.requires_grad or input_flatten.requires_grad or (reference_points is not None and reference_points.requires_grad):
+            return False
     d_model = query.shape[-1]
     return d_model % 64 == 0 and all(lin.weight.dtype == torch.bfloat16 and lin.bias is not None for lin in linears)
 
@@ -251,6 +256,19 @@ def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, l
     if reference_points.shape[-1] not in (2, 4):
         raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
             reference_points.shape[-1]))
+    # the native kernels index these tensors by (B, Lq, n_levels): a broadcastable view must be materialised here
+    if reference_points.dim() != 4 or reference_points.shape[0] not in (1, B) or reference_points.shape[1] not in (1, Lq) or \
+            reference_points.shape[2] not in (1, n_levels):
+        raise RuntimeError(f"msda_layer_forward: reference_points {tuple(reference_points.shape)} does not broadcast to "
+                           f"({B}, {Lq}, {n_levels}, 2|4)")
+    reference_points = reference_points.expand(B, Lq, n_levels, reference_points.shape[-1])
+    if tuple(input_flatten.shape) != (B, S, C):
+        raise RuntimeError(f"msda_layer_forward: input_flatten {tuple(input_flatten.shape)} vs query {tuple(query.shape)}")
+    if tuple(spatial_shapes.shape) != (n_levels, 2) or level_start_index.numel() != n_levels:
+        raise RuntimeError(f"msda_layer_forward: spatial_shapes {tuple(spatial_shapes.shape)} / level_start_index "
+                           f"({level_start_index.numel()}) do not describe {n_levels} levels")
+    if padding_mask is not None and tuple(padding_mask.shape) != (B, S):
+        raise RuntimeError(f"msda_layer_forward: padding mask {tuple(padding_mask.shape)} must be ({B}, {S})")
     L = _lib.lib()
     desc = _lib.VllmMsdaLayerDesc()
     desc.d_model, desc.n_heads, desc.n_levels, desc.n_points = C, n_heads, n_levels, n_points
@@ -273,9 +291,10 @@ def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, l
         _lib.check(-1, "vllm_msda_layer_workspace_bytes")
     ws = _lib.workspace(q.device, nbytes)
     out = torch.empty_like(q)
-    _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
-                                         _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
-                                         ws.numel(), _lib.current_stream(q.device)), "vllm_msda_layer_forward")
+    with torch.cuda.device(q.device):
+        _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
+                                             _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
+                                             ws.numel(), _lib.current_stream(q.device)), "vllm_msda_layer_forward")
     return out
 
 
@@ -320,7 +339,7 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
         if msda_layer_fused_ok(query, input_flatten, self.value_proj, self.sampling_offsets, self.attention_weights,
-                               self.output_proj):   # bf16 inference: the whole layer in one native call
+                               self.output_proj, reference_points=reference_points):   # bf16 inference: one native call
             return msda_layer_forward(query, reference_points, input_flatten, input_spatial_shapes,
                                       input_level_start_index, input_padding_mask, self.value_proj,
                                       self.sampling_offsets, self.attention_weights, self.output_proj, self.n_heads,
@@ -384,7 +403,7 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, num_value, _ = value.shape
         assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == num_value
         if msda_layer_fused_ok(query, value, self.value_proj, self.sampling_offsets, self.attention_weights,
-                               self.output_proj):
+                               self.output_proj, reference_points=reference_points):
             output = msda_layer_forward(query, reference_points, value, spatial_shapes, level_start_index,
                                         key_padding_mask, self.value_proj, self.sampling_offsets,
                                         self.attention_weights, self.output_proj, self.num_heads, self.num_levels,
@@ -454,7 +473,7 @@ class GroundingDinoMultiscaleDeformableAttention(nn.Module):
                 "Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
         if not output_attentions and msda_layer_fused_ok(hidden_states, encoder_hidden_states, self.value_proj,
                                                          self.sampling_offsets, self.attention_weights,
-                                                         self.output_proj):
+                                                         self.output_proj, reference_points=reference_points):
             # (the attention weights stay inside the fused call; ask for output_attentions to get them)
             output = msda_layer_forward(hidden_states, reference_points, encoder_hidden_states, spatial_shapes,
                                         level_start_index, None if attention_mask is None else ~attention_mask,

@@ -46,8 +46,12 @@ def point_sample(input, point_coords, **kwargs):
     x = input.to(torch.float32).contiguous()
     P = pts.shape[1]
     out = torch.empty((N, C, P), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().vllm_point_sample_f32(_lib.ptr(x), _lib.ptr(pts), N, C, H, W, P, _lib.ptr(out),
-                                                _lib.current_stream(x.device)), "vllm_point_sample_f32")
+    if torch.is_grad_enabled() and (input.requires_grad or point_coords.requires_grad):
+        raise RuntimeError("point_sample (native): forward-only kernel -- call under torch.no_grad(); the reference "
+                           "differentiates through F.grid_sample here")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vllm_point_sample_f32(_lib.ptr(x), _lib.ptr(pts), N, C, H, W, P, _lib.ptr(out),
+                                                    _lib.current_stream(x.device)), "vllm_point_sample_f32")
     out = out.to(input.dtype)
     return out.reshape(N, C, point_coords.shape[1], point_coords.shape[2]) if grid else out
 
@@ -61,8 +65,12 @@ def point_sample_masked_mean(input, point_coords, valid):
     x = input.to(torch.float32).contiguous()
     v = valid.to(torch.uint8).contiguous()
     out = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().vllm_point_sample_mean_f32(_lib.ptr(x), _lib.ptr(pts), _lib.ptr(v), N, C, H, W, P, _lib.ptr(out),
-                                                     _lib.current_stream(x.device)), "vllm_point_sample_mean_f32")
+    if torch.is_grad_enabled() and (input.requires_grad or point_coords.requires_grad):
+        # region_encoder.py:135-140 trains mask_embedding through grid_sample; this kernel has no backward
+        raise RuntimeError("point_sample_masked_mean (native): forward-only kernel -- call under torch.no_grad()")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vllm_point_sample_mean_f32(_lib.ptr(x), _lib.ptr(pts), _lib.ptr(v), N, C, H, W, P, _lib.ptr(out),
+                                                         _lib.current_stream(x.device)), "vllm_point_sample_mean_f32")
     return out.to(input.dtype)
 
 

@@ -12,7 +12,8 @@ def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features,
     image_features [n_tiles, T, C] in tile order, split_sizes: tiles per sample ('anyres' list input) or None.
 
     Mirrors the reference's handling of samples without an image (their tiles are dropped, :585-592) and of a
-    token-count mismatch (:597-603: features are repeated / truncated to the number of slots)."""
+    token-count mismatch (:597-603): features are repeated when the slots are a whole multiple of them; any other mismatch
+    raises, as the reference's second assignment does."""
     B, L, C = inputs_embeds.shape
     if not inputs_embeds.is_cuda or inputs_embeds.dtype != torch.bfloat16 or not inputs_embeds.is_contiguous():
         raise RuntimeError("splice_visual_tokens: inputs_embeds must be a contiguous bf16 CUDA tensor")
@@ -23,10 +24,12 @@ def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features,
     vit = image_features[has_image].reshape(-1, C).to(inputs_embeds.dtype).contiguous()
     idx = torch.nonzero(selected.reshape(-1), as_tuple=False).reshape(-1)
     n_sel, n_vit = idx.numel(), vit.shape[0]
-    if n_sel != n_vit and n_vit > 0:
-        vit = vit.repeat(n_sel // n_vit, 1) if n_sel > n_vit else vit[:n_sel]
-        idx = idx[: vit.shape[0]]
-    n = min(idx.numel(), vit.shape[0])
+    if n_sel != n_vit:
+        if n_vit > 0 and n_sel > n_vit and n_sel % n_vit == 0:
+            vit = vit.repeat(n_sel // n_vit, 1)
+        else:
+            raise RuntimeError(f"splice_visual_tokens: shape mismatch: {n_sel} <im_patch> slots cannot take {n_vit} visual tokens")
+    n = idx.numel()
     if n:
         with torch.cuda.device(inputs_embeds.device):
             _lib.check(_lib.lib().vllm_scatter_rows_bf16(_lib.ptr(vit), _lib.ptr(idx.contiguous()), _lib.ptr(inputs_embeds),
