@@ -103,15 +103,19 @@ def msda_bytes(t):
     return 4 * (B * S * M * D + B * Lq * M * L * P * 2 + B * Lq * M * L * P + B * Lq * M * D)
 
 
-def event_time(fn, iters, stream=None):
-    """Average duration (s) of fn() launched `iters` times on the CURRENT torch stream, HIP events."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+def event_time(fn, iters, stream=None, rounds=3):
+    """Average duration (s) of fn() launched `iters` times back to back on the CURRENT torch stream, HIP events; the median of
+    `rounds` such loops (the first loop after an idle gap reads 5-10 % slow while the clocks ramp)."""
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    return float(np.median(ts))
 
 
 def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10):

@@ -357,7 +357,7 @@ def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M):
 
 # ---- the three module mirrors vs the reference's OWN module classes (fixtures: oracle/gen_golden.py::gen_msda_layer) ----
 def _load_layer(g, prefix, mod):
-    sd = {k[len(prefix) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix + ".sd.")}
+    sd = {k[len(prefix) + 4:]: torch.from_numpy(g[k]) for k in list(g.keys()) if k.startswith(prefix + ".sd.")}
     mod.load_state_dict(sd, strict=True)
     return mod.to(DEV).eval()
 

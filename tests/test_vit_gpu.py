@@ -7,7 +7,9 @@ relative) plus accumulation order, so |err| <= 1e-2 * scale.  Assembled encoders
 when it is run in bf16 (i.e. what the reference's own bf16 path would give)."""
 import ast
 import ctypes
+import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -44,11 +46,42 @@ def close(out, ref, tol=1e-2, what=""):
     assert err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
 
 
+def bf16_ulp(x):
+    """Spacing of bf16 numbers at |x| (8 significand bits): 2^(floor(log2 |x|) - 7); the smallest normal's for |x| -> 0."""
+    e = torch.floor(torch.log2(x.abs().double().clamp_min(2.0 ** -126)))
+    return torch.pow(2.0, e - 7)
+
+
+_ULP_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "ulp_table.jsonl")
+
+
+def ulp_close(out, ref, nulp, mag=None, rel_mag=0.0, what=""):
+    """PER-ELEMENT bound for a bf16 kernel output against an fp64 / fp32 reference evaluated on the same bf16-rounded inputs:
+        |out - ref| <= nulp * ulp_bf16(ref) + rel_mag * mag
+    `mag` is the element's natural magnitude (sum of |terms|): the second term covers fp32 accumulation / the rounding of
+    intermediate operands where cancellation makes the result much smaller than its terms; a kernel with ONE final rounding
+    of an exactly accumulated value would need nulp = 0.5 and rel_mag = 0.  The measured maximum (in ulp, after subtracting the
+    magnitude term) is appended to gpurun_out/ulp_table.jsonl (the table in DESIGN.md section 5)."""
+    out, ref = out.double().cpu(), ref.double().cpu()
+    slack = torch.zeros_like(ref) if mag is None else rel_mag * mag.double().cpu()
+    err = (out - ref).abs()
+    u = (err - slack).clamp_min(0) / bf16_ulp(ref)
+    worst = u.max().item()
+    try:
+        os.makedirs(os.path.dirname(_ULP_LOG), exist_ok=True)
+        with open(_ULP_LOG, "a") as f:
+            f.write(json.dumps({"what": what, "max_ulp": round(worst, 3), "bound_ulp": nulp, "rel_mag": rel_mag,
+                                "p999_ulp": round(torch.quantile(u.flatten()[:4_000_000], 0.999).item(), 3)}) + "\n")
+    except OSError:
+        pass
+    assert worst <= nulp, f"{what}: {worst:.2f} bf16 ulp of the reference (bound {nulp}) at {int(u.argmax())}"
+
+
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (577, 1024, 1024), (1000, 3200, 192), (77, 64, 640),
                                    (2 * 577, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("force", [0x100, 0x200, 0x300, 0x400, 0x800])   # 128x128 2-stage, 8-phase 256-row, 8-phase 192-row, 4-wave 256x256x32, 8-phase on 32x32x16
+@pytest.mark.parametrize("force", [0x100, 0x200, 0x300, 0x800])   # 128x128 2-stage, 8-phase 256-row, 8-phase 192-row, 8-phase on 32x32x16
 def test_gemm_epilogues(M, N, K, epi, force):
     torch.manual_seed(M + N + K + epi)
     x = bf(torch.randn(M, K, device=DEV))
@@ -59,18 +92,23 @@ def test_gemm_epilogues(M, N, K, epi, force):
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi | force,
                                          P(ls) if epi == 3 else None, P(res) if epi == 3 else None, N, 0, stream()))
-    z = x.float() @ w.float().t() + b.float()
+    z = x.double() @ w.double().t() + b.double()
+    mag = x.double().abs() @ w.double().abs().t() + b.double().abs()       # natural magnitude of the accumulation
     if epi == 1:
-        z = V.gelu_erf(z)
+        z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))
     elif epi == 2:
-        z = V.quick_gelu(z)
+        z = z * torch.sigmoid(1.702 * z)
     elif epi == 3:
-        z = res.float() + z * ls.float()
+        z = res.double() + z * ls.double()
+        mag = res.double().abs() + mag * ls.double().abs()
     close(y, z, 1e-2, f"gemm epi {epi}")
+    # one rounding to bf16 of an fp32-accumulated value (the activations are evaluated in fp32, |erf err| <= 1.5e-7):
+    # <= 1 bf16 ulp of the reference + 2^-17 of the summed |terms| (fp32 accumulation order)
+    ulp_close(y, z, 1.0, mag, 2.0 ** -17, f"gemm epi={epi} force={force:#x} M{M} N{N} K{K}")
 
 
-@pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512), (0x300, 128), (0x300, 576), (0x400, 128), (0x400, 512),
-                                     (0x400, 576), (0x800, 128), (0x800, 512), (0x800, 576)])
+@pytest.mark.parametrize("force,M", [(0x100, 128), (0x200, 128), (0x200, 512), (0x300, 128), (0x300, 576), (0x800, 128), (0x800, 512),
+                                     (0x800, 576)])
 def test_gemm_transpose_detecting(force, M):
     """A = I-like and asymmetric B (cdna guide G9): catches swapped operands / transposed stores."""
     N = K = M
@@ -93,7 +131,7 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
     b = bf(torch.randn(N, device=DEV))
     ys = []
-    for force in (0x200, 0x200, 0x300, 0x300, 0x100, 0x400, 0x400, 0x800, 0x800):
+    for force in (0x200, 0x200, 0x300, 0x300, 0x100, 0x800, 0x800):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         _lib.check(_lib.lib().vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, force, None, None, 0, 0, stream()))
         ys.append(y)
@@ -102,9 +140,7 @@ def test_gemm256_pipeline_race_screen(M, N, K):
     close(ys[0], ys[4], 4e-3, "256 vs 128 kernel")
     close(ys[2], ys[4], 4e-3, "192 vs 128 kernel")
     assert torch.equal(ys[5], ys[6])
-    close(ys[5], ys[4], 4e-3, "4-wave vs 128 kernel")
-    assert torch.equal(ys[7], ys[8])
-    close(ys[7], ys[4], 4e-3, "8-phase 32x32x16 vs 128 kernel")
+    close(ys[5], ys[4], 4e-3, "8-phase 32x32x16 vs 128 kernel")
     ref = x[:257].float() @ w.float().t() + b.float()
     close(ys[0][:257], ref, 1e-2, "256 kernel vs fp32")
 
@@ -154,9 +190,18 @@ def test_norms(C):
     _lib.check(L.vllm_rmsnorm_bf16(P(x), C, P(w), P(y), C, rows, C, 1e-6, stream()))
     ref = V.rms_norm(x.cpu(), w.cpu(), 1e-6)  # the reference's own bf16 semantics (cast, then * weight)
     close(y, ref, 8e-3, "rmsnorm")
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    r64 = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6)
+    # reference semantics: normalise in fp32, ROUND to bf16, then multiply by the bf16 weight and round again
+    # (modeling_intern_vit.py:40-44): two roundings -> <= 1.5 ulp of the exact product
+    ulp_close(y, r64 * wd, 1.5, None, 0.0, f"rmsnorm C{C}")
     _lib.check(L.vllm_layernorm_bf16(P(x), C, P(w), P(b), P(y), C, rows, C, 1e-5, stream()))
     ref = F.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-5)
     close(y, ref, 8e-3, "layernorm")
+    mu = xd.mean(-1, keepdim=True)
+    n64 = (xd - mu) * torch.rsqrt(((xd - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+    # one rounding of an fp32 evaluation: <= 1 ulp + 2^-20 of (|n w| + |b|) (the affine step cancels when n w ~ -b)
+    ulp_close(y, n64 * wd + bd, 1.0, (n64 * wd).abs() + bd.abs(), 2.0 ** -20, f"layernorm C{C}")
 
 
 def test_qk_rmsnorm_inplace_on_strided_qkv():
@@ -187,6 +232,15 @@ def test_attention_vs_oracle(D, S):
     out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV)
     _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))
     close(out, _attn_ref(qkv.cpu(), H, D, D ** -0.5), 1e-2, f"attention D={D} S={S}")
+    # Per-element bound.  The kernel rounds the probabilities to bf16 before the PV product (relative error 2^-9 each, like
+    # the reference's flash-attn path) and defers the running-max rescale (P up to 2^6 before normalisation, same relative
+    # precision), accumulates in fp32 and rounds the output once:
+    #     |err| <= 1 ulp_bf16(ref) + 2^-8 * sum_j p_j |v_j|
+    q, k, v = qkv.double().cpu().reshape(B, S, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)
+    p = torch.softmax((q * D ** -0.5) @ k.transpose(-2, -1), -1)
+    ref64 = (p @ v).transpose(1, 2)
+    mag = (p @ v.abs()).transpose(1, 2)
+    ulp_close(out, ref64, 1.0, mag, 2.0 ** -8, f"attention D{D} S{S}")
 
 
 @pytest.mark.parametrize("D", [64, 128])
@@ -207,7 +261,7 @@ def test_attention_online_softmax_rescale_branch(D):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
-@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3, 66, 82])
+@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3])
 @pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
 def test_attention_schedule_variants(variant, D, S):
     """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""
