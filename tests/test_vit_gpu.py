@@ -409,17 +409,18 @@ def test_unsupported_head_dim_fails_loudly():
             torch.zeros(1, 3, 56, 56, device=DEV))
 
 
-@pytest.mark.parametrize("arch", ["clip_l", "internvit_wide"])
+@pytest.mark.parametrize("arch", ["clip_l", "clip_l_batch32", "internvit_wide"])
 def test_real_width_encoders_vs_oracle(arch):
-    """ViT-L/14-336 width (2 layers) and InternViT-6B width (2 layers, 448 tiles): S=577 / 1025, d=64 / 128."""
+    """ViT-L/14-336 width (2 layers; also at BASELINE configs[1]'s batch of 32 tiles) and InternViT-6B width (2 layers, 448
+    tiles): S=577 / 1025, d=64 / 128."""
     torch.manual_seed(1)
-    if arch == "clip_l":
+    if arch.startswith("clip_l"):
         from transformers import CLIPVisionConfig
         cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=2,
                     image_size=336, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
         model = CLIPVisionModel(CLIPVisionConfig(**cfgd))
         fwd = lambda s, c, xx: V.clip_vit_forward(s, c, xx, prefix="vision_model.")  # noqa: E731
-        n = 2
+        n = 32 if arch == "clip_l_batch32" else 2
     else:
         cfgd = dict(hidden_size=3200, num_attention_heads=25, intermediate_size=12800, num_hidden_layers=2,
                     image_size=448, patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu",
