@@ -237,6 +237,13 @@ int vllm_pixel_shuffle_bf16(const uint16_t *hidden, long tile_stride, int ld, in
 int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, uint16_t *dst, long n, int C, long dst_rows,
                            vllm_stream_t stream);
 
+/* The per-sample token loops around the LLM (modeling_visionllmv2.py:440-527 [EMB] splice, :609-715 region features and
+ * <region> slots, :775-787 [EMB] hidden states -> text_query) as index bookkeeping + ONE row mover:
+ * dst[dst_idx[i], :] = src[src_idx[i], :] for i < n (device int64 indices; NULL = the identity; rows whose index falls
+ * outside [0, src_rows) / [0, dst_rows) are skipped).  Rows are C bf16, C % 8 == 0. */
+int vllm_copy_rows_bf16(const uint16_t *src, const int64_t *src_idx, uint16_t *dst, const int64_t *dst_idx, long n,
+                        int C, long src_rows, long dst_rows, vllm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * B1. Vision encoder (the `vis_encoder` slot): one call runs patch-embed + all layers.
  *

@@ -269,6 +269,87 @@ def gen_msda_layer():
     np.savez_compressed(os.path.join(OUT, "msda_layer.npz"), **out)
 
 
+def gen_token_loops():
+    """The per-sample token loops of VisionLLMv2Model.forward, executed FROM THE REFERENCE'S OWN STATEMENTS: the method cannot
+    be imported (peft / mmcv / mmdet / detectron2 ...), so the statement ranges are cut out of its AST and exec'd with a
+    stand-in ``self``:
+      * modeling_visionllmv2.py:432-524  [EMB] splice behind the tool tokens (training form: the [EMB] ids are present);
+      * modeling_visionllmv2.py:779-791  [EMB] hidden states -> text_query / text_query_masks."""
+    path = f"{REF}/visionllmv2/model/modeling_visionllmv2.py"
+    tree = ast.parse(open(path).read())
+    fwd = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "VisionLLMv2Model":
+            fwd = next(n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == "forward")
+    assert fwd is not None
+
+    def targets(st):
+        return [t.id for t in getattr(st, "targets", []) if isinstance(t, ast.Name)]
+
+    # (1) splice: from the assignment of emb_ids to the two torch.stack statements, in the method body
+    body = fwd.body
+    i0 = next(i for i, st in enumerate(body) if isinstance(st, ast.Assign) and "emb_ids" in targets(st))
+    i1 = next(i for i, st in enumerate(body) if isinstance(st, ast.Assign) and "inputs_embeds" in targets(st) and i > i0 and
+              "stack" in ast.unparse(st))
+    splice_mod = ast.Module(body=body[i0:i1 + 1], type_ignores=[])
+    ast.fix_missing_locations(splice_mod)
+    splice_code = compile(splice_mod, path, "exec")
+
+    # (2) text_query: the `emb_select = ...` assignment and the first statements of the `if emb_select.sum() != 0` block
+    holders = []
+    for node in ast.walk(fwd):
+        if isinstance(node, ast.If):
+            for k, st in enumerate(node.body):
+                if isinstance(st, ast.Assign) and "emb_select" in targets(st) and "input_ids" in ast.unparse(st):
+                    holders.append((st.lineno, node.body, k))
+    assert holders
+    _, hb, k = min(holders, key=lambda t: t[0])                       # the det / grounding branch (:775-787) comes first
+    inner = next(st for st in hb[k + 1:] if isinstance(st, ast.If))
+    upto = next(i for i, st in enumerate(inner.body) if isinstance(st, ast.For))
+    # (the statement ahead of emb_select unpacks batch_size, seq_len, hidden_size from inputs_embeds.shape)
+    tq_mod = ast.Module(body=[hb[k - 1], hb[k]] + inner.body[:upto + 1], type_ignores=[])
+    ast.fix_missing_locations(tq_mod)
+    tq_code = compile(tq_mod, path, "exec")
+
+    torch.manual_seed(21)
+    B, L, C, NE, NG = 3, 48, 64, 4, 2
+    ids_base = 100
+    tool = dict(det_tool_id=11, seg_tool_id=12, grd_tool_id=13, pose_tool_id=14, gen_tool_id=15, edit_tool_id=16)
+    emb_token_id = 50
+    input_ids = torch.randint(ids_base, ids_base + 30, (B, L))
+    def put(b, pos, tool_id, n):
+        input_ids[b, pos] = tool_id
+        input_ids[b, pos + 1: pos + 1 + n] = torch.arange(emb_token_id, emb_token_id + n) if n == NE else emb_token_id
+    put(0, 3, 11, NE); put(0, 20, 14, NE); put(0, 40, 15, NG)
+    put(1, 10, 12, NE); put(1, 30, 13, NE)
+    put(2, 5, 16, NG)
+    inputs_embeds = torch.randn(B, L, C)
+    tables = {n: torch.randn(NE if n in ("det", "pose") else NG, C) for n in ("det", "pose", "gen", "edit")}
+    self_ = types.SimpleNamespace(emb_token_id=emb_token_id, num_embs=NE, num_embs_gen=NG, **tool,
+                                  **{f"emb_embeddings_{n}": types.SimpleNamespace(weight=t) for n, t in tables.items()})
+    env = {"torch": torch, "self": self_, "input_ids": input_ids.clone(), "inputs_embeds": inputs_embeds.clone(),
+           "gap_len": NE, "gap_len_gen": NG}
+    exec(splice_code, env)
+    out_ids, out_emb = env["input_ids"], env["inputs_embeds"]
+
+    hidden = torch.randn(B, L, C)
+    # (a det / grounding sample carries only [EMB] blocks of num_embs tokens: drop the 2-token generation blocks; sample 2
+    # then has no [EMB] token at all -> an all-zero, fully masked row)
+    tq_ids = out_ids.clone()
+    for b, pos in ((0, 40), (2, 5)):
+        tq_ids[b, pos: pos + 1 + NG] = ids_base
+    env2 = {"torch": torch, "self": self_, "input_ids": tq_ids.clone(), "inputs_embeds": out_emb, "hidden_states": hidden}
+    exec(tq_code, env2)
+    print("token loops: splice changed", int((out_emb != inputs_embeds).any(-1).sum()), "rows; text_query", tuple(env2["text_query"].shape))
+    np.savez_compressed(os.path.join(OUT, "token_loops.npz"), input_ids=input_ids.numpy(), inputs_embeds=inputs_embeds.numpy(),
+                        emb_token_id=np.array(emb_token_id), num_embs=np.array(NE), num_embs_gen=np.array(NG),
+                        tool_ids=np.array([tool[k] for k in ("det_tool_id", "seg_tool_id", "grd_tool_id", "pose_tool_id", "gen_tool_id", "edit_tool_id")]),
+                        table_det=tables["det"].numpy(), table_pose=tables["pose"].numpy(), table_gen=tables["gen"].numpy(),
+                        table_edit=tables["edit"].numpy(), out_ids=out_ids.numpy(), out_embeds=out_emb.numpy(),
+                        hidden_states=hidden.numpy(), tq_input_ids=tq_ids.numpy(), text_query=env2["text_query"].numpy(),
+                        text_query_masks=env2["text_query_masks"].numpy())
+
+
 def gen_dcnv3():
     """DCNv3 forward: the reference's pure-PyTorch twin on the inputs of its own test (ops_dcnv3/test.py:19-66, seed 3:
     N=2, 8x8, M=4, D=16, 3x3, offset_scale 2, pad 1) plus strided / dilated / non-square cases."""
@@ -476,6 +557,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_msda()
     gen_msda_layer()
+    gen_token_loops()
     gen_dcnv3()
     gen_point_sample()
     gen_intern_vit()

@@ -261,7 +261,7 @@ def test_attention_online_softmax_rescale_branch(D):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
-@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3])
+@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3, 18])   # 18: no padding trim
 @pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
 def test_attention_schedule_variants(variant, D, S):
     """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""

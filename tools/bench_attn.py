@@ -30,5 +30,6 @@ def run(n, S, H, D, variants=(2,), rounds=7, reps=20):
 
 if __name__ == "__main__":
     # 16 + v: the same schedule without the padding trim (short last key tile, idle padding waves)
-    run(40, 577, 16, 64, variants=(66, 2, 82, 18, 3, 32))   # 64 + v: two query row groups per wave
-    run(8, 1025, 25, 128, variants=(3, 19, 2, 18, 32))
+    run(40, 577, 16, 64, variants=(2, 18, 3, 32))   # 16 + v: the same schedule without the padding trim   # 64 + v: folded schedule (max subtraction on the MFMA, lagged max)
+    run(8, 1025, 25, 128, variants=(2, 3, 32))
+    run(40, 1025, 25, 128, variants=(2, 32))

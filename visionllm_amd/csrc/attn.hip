@@ -391,6 +391,7 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
                      a.v_hs % 8 == 0 && a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0,
                  "attn: q/k/v must be 16-byte aligned with strides multiple of 8 elements");
     a.nqt = (a.S + QBLK - 1) / QBLK;
+    a.row0 = 0;
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;

@@ -106,6 +106,22 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const uint16_t *__res
     }
 }
 
+// dst[di[i], :] = src[si[i], :]; a null index means the identity.  One 16-byte chunk per lane, rows of C bf16.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint16_t *__restrict__ src, const int64_t *__restrict__ si,
+                                                        uint16_t *__restrict__ dst, const int64_t *__restrict__ di, long n, int C,
+                                                        long src_rows, long dst_rows)
+{
+    const int cch = C / 8;
+    const long nchunks = n * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % cch);
+        const long r = i / cch;
+        const long s = si ? si[r] : r, d = di ? di[r] : r;
+        if (s >= 0 && s < src_rows && d >= 0 && d < dst_rows)
+            *reinterpret_cast<uint4_t *>(dst + d * C + ck * 8) = *reinterpret_cast<const uint4_t *>(src + s * C + ck * 8);
+    }
+}
+
 static inline unsigned grid_for(long n)
 {
     long b = (n + 255) / 256;
@@ -174,6 +190,18 @@ extern "C" int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, u
     VLLM_LAUNCH(scatter_rows_kernel, dim3(grid_for(n * (C / 8))), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, C,
                 dst_rows);
     VLLM_CHECK_LAUNCH("scatter_rows_kernel");
+    return VLLM_OK;
+}
+
+extern "C" int vllm_copy_rows_bf16(const uint16_t *src, const int64_t *src_idx, uint16_t *dst, const int64_t *dst_idx, long n,
+                                   int C, long src_rows, long dst_rows, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(n >= 0 && C > 0 && C % 8 == 0, "copy_rows: C must be a positive multiple of 8");
+    if (n == 0) return VLLM_OK;
+    VLLM_REQUIRE(src && dst && aligned16(src) && aligned16(dst), "copy_rows: null or unaligned pointer");
+    VLLM_LAUNCH(copy_rows_kernel, dim3(grid_for(n * (C / 8))), dim3(256), 0, (hipStream_t)stream, src, src_idx, dst, dst_idx, n, C,
+                src_rows, dst_rows);
+    VLLM_CHECK_LAUNCH("copy_rows_kernel");
     return VLLM_OK;
 }
 

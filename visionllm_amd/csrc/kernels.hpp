@@ -59,6 +59,7 @@ struct AttnArgs {
     int q_hs, k_hs, v_hs;       // head strides
     int B, S, H;
     int nqt;                    // query tiles per (b, h) (filled by the launcher)
+    int row0;                   // first query row of this launch (filled by the launcher)
     int no_trim;                // 1: process padding keys / padding query waves like live ones (A/B switch; launcher)
     float scale_log2e;
 };

@@ -36,3 +36,112 @@ def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features,
                                                          n, C, B * L, _lib.current_stream(inputs_embeds.device)),
                        "vllm_scatter_rows_bf16")
     return inputs_embeds
+
+
+# ---- the other per-sample token loops around the LLM: index bookkeeping in torch, row movement
+# ---- by ONE native kernel (vllm_copy_rows_bf16: dst[dst_idx[i]] = src[src_idx[i]]) ------------------------------------------
+def _copy_rows(src, src_idx, dst, dst_idx, n):
+    """dst / src: contiguous bf16 CUDA tensors viewed as rows of C; indices: int64 CUDA tensors or None (identity)."""
+    C = src.shape[-1]
+    if not (src.is_cuda and dst.is_cuda and src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and
+            src.is_contiguous() and dst.is_contiguous() and dst.shape[-1] == C):
+        raise RuntimeError("copy_rows: contiguous bf16 CUDA tensors with equal row length required")
+    if n == 0:
+        return dst
+    si = None if src_idx is None else src_idx.to(torch.int64).contiguous()
+    di = None if dst_idx is None else dst_idx.to(torch.int64).contiguous()
+    with torch.cuda.device(dst.device):
+        _lib.check(_lib.lib().vllm_copy_rows_bf16(_lib.ptr(src), _lib.ptr(si), _lib.ptr(dst), _lib.ptr(di), int(n), C,
+                                                  src.numel() // C, dst.numel() // C, _lib.current_stream(dst.device)),
+                   "vllm_copy_rows_bf16")
+    return dst
+
+
+def splice_emb_tokens(input_ids, inputs_embeds, tool_tables, emb_token_id, num_embs, num_embs_gen=None, gen_tools=()):
+    """[EMB] splice (modeling_visionllmv2.py:425-527), the training / prefill form in which the [EMB] tokens are already
+    present in ``input_ids`` (gap_len = num_embs): behind every tool token the next ``num_embs`` rows of ``inputs_embeds``
+    are REPLACED by that tool's learned query table and the ids by the [EMB] id range.
+
+    ``tool_tables``: ordered ``{tool_token_id: table [num_embs, C]}`` in the reference's order of application (det, seg,
+    grd -> emb_embeddings_det; pose -> emb_embeddings_pose; gen -> emb_embeddings_gen; edit -> emb_embeddings_edit); tool ids
+    listed in ``gen_tools`` use ``num_embs_gen`` rows and the single id ``emb_token_id`` (:436).  Returns
+    (input_ids, inputs_embeds): ids as a new tensor, embeddings modified IN PLACE.  A table that would run past the end of
+    the sequence raises (the reference's torch.stack of unequal lengths does)."""
+    B, L, C = inputs_embeds.shape
+    ids = input_ids.clone()
+    flat = inputs_embeds.view(B * L, C)
+    for tool_id, table in tool_tables.items():
+        n_rows = num_embs_gen if tool_id in gen_tools else num_embs
+        if table.shape[0] != n_rows:
+            raise RuntimeError(f"splice_emb_tokens: table of tool {tool_id} has {table.shape[0]} rows, expected {n_rows}")
+        pos = torch.nonzero(input_ids == tool_id, as_tuple=False)            # [n, 2] (batch, position)
+        if pos.numel() == 0:
+            continue
+        if int((pos[:, 1] + n_rows).max()) >= L:
+            raise RuntimeError("splice_emb_tokens: [EMB] block runs past the end of the sequence")
+        offs = torch.arange(1, n_rows + 1, device=pos.device)
+        dst = ((pos[:, 0] * L + pos[:, 1])[:, None] + offs[None, :]).reshape(-1)             # flattened target rows
+        src = offs.sub(1).repeat(pos.shape[0])                                               # table rows, repeated per tool token
+        _copy_rows(table.detach().to(inputs_embeds.dtype).contiguous(), src, flat, dst, dst.numel())
+        new_ids = (torch.full((n_rows,), emb_token_id, device=ids.device, dtype=ids.dtype) if tool_id in gen_tools else
+                   torch.arange(emb_token_id, emb_token_id + n_rows, device=ids.device, dtype=ids.dtype))
+        ids.view(-1)[dst] = new_ids.repeat(pos.shape[0])
+    return ids, inputs_embeds
+
+
+def gather_emb_hidden_states(hidden_states, input_ids, emb_token_id, num_embs):
+    """[EMB] hidden states -> the det head's text_query (modeling_visionllmv2.py:775-787): returns
+    (text_query [B, max_patches, num_embs, C] zero padded, text_query_masks [B, max_patches] bool), or (None, None) when no
+    [EMB] token is present.  The reference loops over the batch; here the k-th selected token of sample b goes to row
+    b * max_patches * num_embs + k in one native row copy (one host read of the patch counts, as the reference's .max())."""
+    B, L, C = hidden_states.shape
+    sel = (input_ids >= emb_token_id) & (input_ids <= emb_token_id + num_embs - 1)
+    counts = sel.sum(-1)
+    total = int(counts.sum())
+    if total == 0:
+        return None, None
+    num_patches = counts // num_embs
+    max_p = int(num_patches.max())
+    out = torch.zeros((B, max_p, num_embs, C), dtype=hidden_states.dtype, device=hidden_states.device)
+    masks = torch.arange(max_p, device=hidden_states.device)[None, :] < num_patches[:, None]
+    if max_p == 0:
+        return out, masks
+    rank = sel.cumsum(-1) - 1                                                   # position of a selected token within its sample
+    keep = sel & (rank < (num_patches * num_embs)[:, None])                     # (the reference's reshape(-1, num_embs, C) needs whole patches)
+    if bool((counts % num_embs != 0).any()):
+        raise RuntimeError("gather_emb_hidden_states: a sample's [EMB] tokens are not a whole number of patches")
+    src = torch.nonzero(keep.reshape(-1), as_tuple=False).reshape(-1)
+    b_of = src // L
+    dst = b_of * (max_p * num_embs) + rank.reshape(-1)[src]
+    _copy_rows(hidden_states.contiguous().view(B * L, C), src, out.view(-1, C), dst, src.numel())
+    return out, masks
+
+
+def gather_region_image_features(hidden_states, split_sizes, num_regions, levels=(-3, -2, -1)):
+    """Region branch, feature selection (modeling_visionllmv2.py:655-676, 'anyres' input): for every region of sample i the
+    GLOBAL tile's features (the last split of the sample) without CLS, at the last three encoder levels.
+    hidden_states: indexable of [n_tiles, 1 + T, C] bf16; -> list of [n_all_regions, T, C] (one native row gather per level)."""
+    outs = []
+    dev = hidden_states[levels[0]].device
+    last_tile = torch.tensor([sum(split_sizes[: i + 1]) - 1 for i in range(len(split_sizes))], device=dev, dtype=torch.int64)
+    tile_of_region = last_tile.repeat_interleave(torch.as_tensor(num_regions, device=dev))
+    for lv in levels:
+        hs = hidden_states[lv].contiguous()
+        n, S1, C = hs.shape
+        T = S1 - 1
+        src = (tile_of_region[:, None] * S1 + 1 + torch.arange(T, device=dev)[None, :]).reshape(-1)
+        out = torch.empty((tile_of_region.numel(), T, C), dtype=hs.dtype, device=dev)
+        _copy_rows(hs.view(n * S1, C), src, out.view(-1, C), None, src.numel())
+        outs.append(out)
+    return outs
+
+
+def splice_region_tokens(inputs_embeds, input_ids, reg_token_id, region_features):
+    """<region> slots (modeling_visionllmv2.py:688-695): inputs_embeds[input_ids == reg_token_id] = region_features, in place."""
+    B, L, C = inputs_embeds.shape
+    dst = torch.nonzero((input_ids == reg_token_id).reshape(-1), as_tuple=False).reshape(-1)
+    feats = region_features.to(inputs_embeds.dtype).reshape(-1, C).contiguous()
+    if dst.numel() != feats.shape[0]:
+        raise RuntimeError(f"splice_region_tokens: {dst.numel()} <region> slots cannot take {feats.shape[0]} region features")
+    _copy_rows(feats, None, inputs_embeds.view(B * L, C), dst, dst.numel())
+    return inputs_embeds
