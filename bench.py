@@ -118,7 +118,7 @@ def event_time(fn, iters, stream=None, rounds=3):
     return float(np.median(ts))
 
 
-def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10):
+def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload="vitl"):
     """Achieved vs peak of every hot kernel of the workload, each launched alone (HIP events on torch's current stream =
     the stream the C ABI launches on) + its launches per step.  cfg: VIT or IVIT; bridge_dims: [(M, N, K), ...]."""
     from visionllm_amd import _lib
@@ -177,7 +177,7 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            tr = json.load(open(pmc))
+            tr = json.load(open(pmc)).get(workload, {})
             for k in out:
                 if k in tr:
                     out[k]["traffic"] = tr[k]
@@ -400,7 +400,7 @@ def main():
         T = (cfg["image_size"] // cfg["patch_size"]) ** 2
         bdims = ([(n_tiles * T // 4, LLM_HIDDEN, 4 * cfg["hidden_size"]), (n_tiles * T // 4, LLM_HIDDEN, LLM_HIDDEN)] if ivit else
                  [(n_tiles * T, LLM_HIDDEN, cfg["hidden_size"]), (n_tiles * T, LLM_HIDDEN, LLM_HIDDEN)])
-        rl = kernel_rooflines(dev, msda_in, n_tiles, cfg, bdims)
+        rl = kernel_rooflines(dev, msda_in, n_tiles, cfg, bdims, workload=args.workload)
         step_us = dt / args.steps * 1e6
         for v in rl.values():
             v["share_of_step"] = v["launches_per_step"] * v["us_per_launch"] / step_us

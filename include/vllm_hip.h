@@ -47,6 +47,10 @@ int vllm_device_info(char *name, int cap);
  * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).
  * "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted
  * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).
+ * "msda_layer_fused": 1 (default) vllm_msda_layer_forward runs sampling_offsets + attention_weights as one GEMM whose
+ * epilogue does the softmax and the location arithmetic, and takes the operator's result in bf16 straight from the
+ * LDS-tiled kernel (needs L * P == 16, P even; other layers compose automatically); 0 the explicit composition (two GEMMs,
+ * prep kernel, fp32 operator, conversion pass) -- the A/B reference, same results to fp32 rounding.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */

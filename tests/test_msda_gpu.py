@@ -269,6 +269,40 @@ def test_edge_cases_and_errors():
                                  torch.zeros(1, 1, 2, 1, 2, device=DEV), 64)
 
 
+@pytest.mark.parametrize("Lq", [29, None])   # gather kernels / encoder shape (Lq == S: LDS-tiled kernels)
+def test_empty_level_adds_nothing_and_touches_no_memory(Lq):
+    """A level with H == 0 or W == 0: the reference accepts the point (h_im = -0.5 > -1, ms_deform_im2col_cuda.cuh:277-292)
+    but every corner test fails, so the level contributes exactly zero and no address is formed.  (the
+    clamped unconditional loads would have read index -1.)"""
+    shapes = [(6, 8), (0, 5), (3, 4), (2, 0)]
+    S = 48 + 12
+    lq = S if Lq is None else Lq
+    rng = np.random.default_rng(1)
+    value = rng.standard_normal((2, S, 8, 32)).astype(np.float32)
+    loc = (rng.random((2, lq, 8, 4, 4, 2)) * 1.1 - 0.05).astype(np.float32)
+    attw = rng.random((2, lq, 8, 4, 4)).astype(np.float32)
+    ss = np.array(shapes, dtype=np.int64)
+    lsi = np.array([0, 48, 48, 60], dtype=np.int64)
+    ref = O.forward(value.astype(np.float64), ss, lsi, loc.astype(np.float64), attw.astype(np.float64))
+    out = A.ms_deform_attn_forward(_t(value), _t(ss), _t(lsi), _t(loc), _t(attw), 64)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.reshape(out.shape), rtol=1e-4, atol=1e-4)
+    out64 = A.ms_deform_attn_forward(_t(value).double(), _t(ss), _t(lsi), _t(loc).double(), _t(attw).double(), 64)
+    np.testing.assert_allclose(out64.cpu().numpy(), ref.reshape(out.shape), rtol=1e-12, atol=1e-12)
+    # the two live levels alone give the same answer: the empty ones added nothing
+    keep = [0, 2]
+    ref2 = O.forward(value.astype(np.float64), ss[keep], np.array([0, 48]), loc[:, :, :, keep].astype(np.float64),
+                     attw[:, :, :, keep].astype(np.float64))
+    np.testing.assert_allclose(ref, ref2, rtol=0, atol=1e-12)
+    go = rng.standard_normal((2, lq, 256)).astype(np.float32)
+    gv, gl, gw = A.ms_deform_attn_backward(_t(value), _t(ss), _t(lsi), _t(loc), _t(attw), _t(go), 64)
+    assert torch.isfinite(gv).all()
+    assert (gl[:, :, :, [1, 3]] == 0).all() and (gw[:, :, :, [1, 3]] == 0).all()
+    rv, rl, rw = O.backward(value.astype(np.float64), ss, lsi, loc.astype(np.float64), attw.astype(np.float64),
+                            go.astype(np.float64))
+    np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(gw.cpu().numpy(), rw, rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("channels", [4, 30, 32, 64, 71, 1025])  # the reference's gradcheck list (:139-146)
 def test_backward_vs_oracle_f64(channels):
     N, M, Lq, L, P = 1, 2, 2, 2, 2
@@ -669,6 +703,35 @@ def test_fused_layer_vs_oracle(shapes, Lq, ref_dim, four_d):
     # internal tensors are fp32, so we must be at least as close to the fp64 truth as the reference's bf16 arithmetic
     assert err <= max(err_ref * 1.05, 4e-3), (err, err_ref)
     assert np.abs(o - truth).max() <= 2e-2 * np.abs(truth).max()
+
+
+@pytest.mark.parametrize("shapes,Lq,ref_dim,four_d,M", [
+    ([(20, 24), (10, 12), (5, 6), (3, 3)], 77, 2, 0, 8),       # L * P == 16: query GEMM with the sampling epilogue
+    ([(20, 24), (10, 12), (5, 6), (3, 3)], 130, 4, 0, 8),      # boxes
+    ([(20, 24), (10, 12), (5, 6), (3, 3)], 61, 4, 1, 4),       # UniPose 4D normalizer, 4 heads (N = 192)
+    ([(40, 48), (20, 24), (10, 12), (5, 6)], None, 2, 0, 8),   # pyramid + Lq == S: operator writes bf16 itself
+    ([(41, 48), (20, 24), (10, 12), (5, 6)], None, 2, 0, 8),   # not a pyramid: fp32 operator + conversion pass
+])
+def test_fused_layer_sampling_epilogue_matches_composition(shapes, Lq, ref_dim, four_d, M):
+    """msda_layer_fused 1 (one query GEMM with the softmax / location epilogue, bf16 operator output) against 0 (two GEMMs +
+    prep kernel + fp32 operator + conversion pass): the same arithmetic, operation for operation, in a different launch
+    structure -> the same bits."""
+    from visionllm_amd import _lib
+    mod, q, ref, src, ss, lsi, mask = _layer_case(2, shapes, Lq, ref_dim, four_d, seed=11 + ref_dim + M, M=M, C=32 * M)
+    with torch.no_grad():
+        old = _lib.lib().vllm_set_option(b"msda_layer_fused", 0)
+        try:
+            composed = mod(q, ref, src, ss, lsi, mask)
+            _lib.lib().vllm_set_option(b"msda_layer_fused", 1)
+            fused = mod(q, ref, src, ss, lsi, mask)
+        finally:
+            _lib.lib().vllm_set_option(b"msda_layer_fused", old)
+    assert torch.isfinite(fused.float()).all()
+    assert torch.equal(fused, composed), float((fused.float() - composed.float()).abs().max())
+    truth, ref_bf16 = _layer_truth(mod, q, ref, src, ss, lsi, mask)
+    o = fused.double().cpu().numpy()
+    rms = np.sqrt((truth ** 2).mean())
+    assert np.sqrt(((o - truth) ** 2).mean()) / rms <= max(np.sqrt(((ref_bf16 - truth) ** 2).mean()) / rms * 1.05, 4e-3)
 
 
 def test_fused_layer_module_flavours_and_fallbacks():

@@ -28,6 +28,12 @@ def timeit(fn, iters=10, warmup=3):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="both", choices=["both", "encoder", "decoder"])
+    ap.add_argument("--only", default="all", choices=["all", "fused", "round1"],
+                    help="time only one launch structure (for a rocprofv3 --kernel-trace --stats run of that structure)")
+    args = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
     B, C, M, L, P = 8, 256, 8, 4, 4
@@ -39,6 +45,8 @@ def main():
     lsi = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
     src = torch.randn(B, S, C, device=dev).to(torch.bfloat16)
     for name, Lq in (("encoder", S), ("decoder", 900)):
+        if args.case not in ("both", name):
+            continue
         q = torch.randn(B, Lq, C, device=dev).to(torch.bfloat16)
         if Lq == S:   # encoder self-attention: a query's reference point is its own pixel centre (...mask_dn.py:1579-1606)
             pts = []
@@ -49,7 +57,15 @@ def main():
         else:
             ref = torch.rand(B, Lq, L, 2, device=dev)
         with torch.no_grad():
+            from visionllm_amd import _lib
+            if args.only != "all":
+                _lib.lib().vllm_set_option(b"msda_layer_fused", 1 if args.only == "fused" else 0)
+                print(json.dumps(dict(case=name, structure=args.only, us=timeit(lambda: mod(q, ref, src, ss, lsi, None)) * 1e6)))
+                continue
             fused = timeit(lambda: mod(q, ref, src, ss, lsi, None))
+            _lib.lib().vllm_set_option(b"msda_layer_fused", 0)   # round-1 launch structure: 2 query GEMMs + prep + cvt
+            fused_r1 = timeit(lambda: mod(q, ref, src, ss, lsi, None))
+            _lib.lib().vllm_set_option(b"msda_layer_fused", 1)
             ok = A.msda_layer_fused_ok
             A.msda_layer_fused_ok = lambda *a, **k: False
             try:
@@ -57,7 +73,7 @@ def main():
             finally:
                 A.msda_layer_fused_ok = ok
         flops = 2.0 * B * C * (S * C + Lq * (M * L * P * 3) + Lq * C)
-        print(json.dumps(dict(case=name, B=B, Lq=Lq, fused_us=fused * 1e6, composed_us=composed * 1e6,
+        print(json.dumps(dict(case=name, B=B, Lq=Lq, fused_us=fused * 1e6, fused_round1_structure_us=fused_r1 * 1e6, composed_us=composed * 1e6,
                               speedup=composed / fused, gemm_gflop=flops / 1e9)))
 
 

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/pmc_traffic.json (HBM bytes per launch).
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/pmc_traffic.json (HBM bytes per launch, per bench workload).
+
+    python tools/collect_pmc.py <fetch_dir> <write_dir> <out.json> [vitl|internvit6b]
 
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes of a
 wide coalesced read stream, so reads are doubled; both counters are in KiB.  Gather-heavy kernels (MSDA) are not a wide
@@ -11,7 +13,11 @@ import json
 import os
 import sys
 
-KEY = {"msda_fwd_tiled4": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<2,": "gemm", "gemm256_bf16_kernelILi2": "gemm"}
+# kernel-name fragments -> bench.py roofline keys ("gemm" = MLP fc1: the quick_gelu (ViT-L) / gelu (InternViT) epilogue instance)
+KEYS = {"vitl": {"msda_fwd_tiled7": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<2,": "gemm",
+                 "gemm256_bf16_kernelILi2": "gemm"},
+        "internvit6b": {"msda_fwd_tiled7": "msda", "attn_fwd_kernel": "attn", "gemm256_bf16_kernel<1,": "gemm",
+                        "gemm256_bf16_kernelILi1": "gemm"}}
 
 
 def load(d):
@@ -23,7 +29,8 @@ def load(d):
     return agg
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, workload="vitl"):
+    KEY = KEYS[workload]
     res = {}
     raw = {}
     for d in (fetch_dir, write_dir):
@@ -35,10 +42,17 @@ def main(fetch_dir, write_dir, out):
     for key, c in raw.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             res[key] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    json.dump(res, open(out, "w"), indent=1)
-    json.dump(raw, open(out.replace(".json", "_raw.json"), "w"), indent=1)
+    def merge(path, val):   # one file, one entry per workload
+        try:
+            cur = json.load(open(path))
+        except Exception:
+            cur = {}
+        cur[workload] = val
+        json.dump(cur, open(path, "w"), indent=1)
+    merge(out, res)
+    merge(out.replace(".json", "_raw.json"), raw)
     print(json.dumps({"traffic_bytes_per_launch": res, "raw_KiB": raw}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(*sys.argv[1:5])

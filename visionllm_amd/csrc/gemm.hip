@@ -48,6 +48,13 @@ __device__ __forceinline__ void stage_tile(const uint16_t *__restrict__ src, int
     }
 }
 
+// value of lane (quad_perm CTRL) of the same quad: 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs a)
 {
@@ -79,8 +86,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / BK;
+    const uint16_t *Wsrc = a.W;
+    if (EPI == EPI_MSDA && n0 >= a.nsplit) Wsrc = a.W2 - (size_t)a.nsplit * a.ldw;   // second weight matrix (tile-uniform)
     stage_tile(a.X, a.ldx, m0, a.M, 0, smem, wave, lane, a.xP);
-    stage_tile(a.W, a.ldw, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile(Wsrc, a.ldw, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
         char *nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nk) {
             stage_tile(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nxt, wave, lane, a.xP);
-            stage_tile(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            stage_tile(Wsrc, a.ldw, n0, a.N, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
         }
         const char *xs = cur, *ws = cur + TILE_BYTES;
 #pragma unroll
@@ -113,6 +122,73 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_F32 || EPI == EPI_MSDA) {
+        // ---- fp32 epilogues go through LDS: the accumulator layout would store 64-byte pieces of 16 different rows per
+        // instruction (and an fp32 tile is all output traffic: these GEMMs are HBM-bound); re-read row-wise, a wave stores
+        // two full 512-byte rows per instruction.  The ring is free after the K loop's last barrier: 128 x 512 B = 64 KiB.
+        // 16-byte chunk c of row r lives at chunk c ^ (r & 15): conflict-free on the write side (16 rows per ds_write_b128
+        // group) and on the read side (32 chunks of one row).
+        float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + fr, chunk = wn * 16 + i * 4 + kq;
+                *reinterpret_cast<f32x4_t *>(ct + row * 128 + ((chunk ^ (row & 15)) << 2)) = acc[i][j];
+            }
+        __syncthreads();
+        const int c = lane & 31, n = n0 + c * 4;
+        const bool nok = n < a.N;
+        const EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
+        // EPI_MSDA (MSDeformAttn.forward ms_deform_attn.py:110-129 on the accumulator): per-lane constants of column n
+        const bool is_off = EPI == EPI_MSDA && n < a.nsplit;
+        // (the arithmetic below is msda_prep_kernel's, operation for operation: the two launch structures give the same bits)
+        int lvl = 0;
+        float Wl = 1.f, Hl = 1.f;
+        if (EPI == EPI_MSDA && is_off) {   // offsets in (head, level, point, xy) order: two points of level lvl
+            lvl = (n / (2 * a.mP)) % a.mL;
+            Wl = (float)a.shapes[2 * lvl + 1];
+            Hl = (float)a.shapes[2 * lvl];
+        }
+        const float invW = 1.f / Wl, invH = 1.f / Hl;
+        const uint8_t *mask = EPI == EPI_F32 ? reinterpret_cast<const uint8_t *>(a.res) : nullptr;
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int row = p * 8 + wave * 2 + (lane >> 5);
+            const int m = m0 + row;
+            const bool live = nok && m < a.M;
+            const int mc = m < a.M ? m : a.M - 1;
+            const f32x4_t t = *reinterpret_cast<const f32x4_t *>(ct + row * 128 + ((c ^ (row & 15)) << 2));
+            float v[4] = {t[0] + cols.bia[0], t[1] + cols.bia[1], t[2] + cols.bia[2], t[3] + cols.bia[3]};
+            if (EPI == EPI_F32) {
+                const bool dead = mask && mask[mc] != 0;   // key-padding mask: zero rows (ms_deform_attn.py:106-109)
+                const float4_t o4 = {dead ? 0.f : v[0], dead ? 0.f : v[1], dead ? 0.f : v[2], dead ? 0.f : v[3]};
+                if (live) *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(a.Y) + (size_t)m * a.ldy + n) = o4;
+            } else if (is_off) {
+                const float *r = a.ref + ((size_t)mc * a.mL + lvl) * a.ref_dim;
+                float sx, sy;
+                if (a.ref_dim == 2) { sx = invW; sy = invH; }
+                else if (a.four_d) { sx = r[2] * 0.5f / Wl; sy = r[3] * 0.5f / Hl; }
+                else { sx = r[2] * 0.5f / (float)a.mP; sy = r[3] * 0.5f / (float)a.mP; }
+                const float rx = r[0], ry = r[1];
+                const float4_t o4 = {rx + v[0] * sx, ry + v[1] * sy, rx + v[2] * sx, ry + v[3] * sy};
+                if (live) *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(a.Y) + (size_t)m * a.ldy + n) = o4;
+            } else {   // the L * P == 16 logits of one head are the 4 lanes of a quad: softmax with two DPP exchanges
+                float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                mx = fmaxf(mx, quad_xchg<0xB1>(mx));
+                mx = fmaxf(mx, quad_xchg<0x4E>(mx));
+                float e[4], sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[k] = __expf(v[k] - mx); sum += e[k]; }
+                sum += quad_xchg<0xB1>(sum);
+                sum += quad_xchg<0x4E>(sum);
+                const float inv = 1.f / sum;
+                const float4_t o4 = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+                if (live) *reinterpret_cast<float4_t *>(a.Y2 + (size_t)m * a.ldy2 + (n - a.nsplit)) = o4;
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds features n..n+3 (rows of the swapped product) of token m ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -137,10 +213,17 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     VLLM_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     VLLM_REQUIRE(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
     VLLM_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0 && a.ldy % 4 == 0 && aligned16(a.X) && aligned16(a.W) &&
-                     (reinterpret_cast<uintptr_t>(a.Y) & (epi == EPI_F32 ? 15u : 7u)) == 0,
+                     (reinterpret_cast<uintptr_t>(a.Y) & (epi == EPI_F32 || epi == EPI_MSDA ? 15u : 7u)) == 0,
                  "gemm: operands must be 16-byte aligned with row strides multiple of 8 elements");
     VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
     VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
+    if (epi == EPI_MSDA) {
+        VLLM_REQUIRE(a.W2 && a.Y2 && a.ref && a.shapes && a.mL > 0 && a.mP > 0 && a.mP % 2 == 0 && a.mL * a.mP == 16 &&
+                         a.nsplit % BN == 0 && a.nsplit > 0 && a.nsplit < a.N && (a.N - a.nsplit) % 16 == 0 && a.ldy2 % 4 == 0 &&
+                         aligned16(a.W2) && aligned16(a.Y2) && aligned16(a.Y) && (a.ref_dim == 2 || a.ref_dim == 4),
+                     "gemm: bad operands for the MSDA sampling epilogue");
+        a.variant = 1;
+    }
     if (a.variant == 4) { a.variant = 2; a.variant256 = 5; }   // 8-phase schedule on the 32x32x16 instruction
     VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");
     if (a.variant != 1 && (a.variant == 2 || (a.N >= 1024 && a.M >= 1024)))
@@ -160,6 +243,7 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     case EPI_RESIDUAL: L(EPI_RESIDUAL); break;
     case EPI_EMBED: L(EPI_EMBED); break;
     case EPI_F32: L(EPI_F32); break;
+    case EPI_MSDA: L(EPI_MSDA); break;
     default: set_error("gemm: unknown epilogue %d", epi); return VLLM_EINVAL;
     }
 #undef L

@@ -36,8 +36,10 @@ __device__ __forceinline__ EpiCols epi_cols(const GemmArgs &a, int n)
     EpiCols c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { c.bia[r] = 0.f; c.scl[r] = 1.f; }
-    if (a.bias) {
-        const uint2_t b = *reinterpret_cast<const uint2_t *>(a.bias + n);
+    const uint16_t *bias = a.bias;
+    if (EPI == EPI_MSDA && n >= a.nsplit) bias = a.bias2 ? a.bias2 - a.nsplit : nullptr;
+    if (bias) {
+        const uint2_t b = *reinterpret_cast<const uint2_t *>(bias + n);
         c.bia[0] = bf16lo_to_f32(b.x); c.bia[1] = bf16hi_to_f32(b.x); c.bia[2] = bf16lo_to_f32(b.y); c.bia[3] = bf16hi_to_f32(b.y);
     }
     if (EPI == EPI_RESIDUAL && a.scale) {

@@ -11,6 +11,7 @@ enum GemmEpilogue : int {
     EPI_RESIDUAL = VLLM_EPI_RESIDUAL,
     EPI_EMBED = VLLM_EPI_EMBED,
     EPI_F32 = VLLM_EPI_F32,
+    EPI_MSDA = 100,   // internal (msda_layer.hip): offsets -> sampling locations, logits -> softmax weights, both fp32
 };
 
 struct GemmArgs {
@@ -28,12 +29,20 @@ struct GemmArgs {
     int variant;            // 0 auto, 1 force 128x128 kernel, 2 force 256x256 8-phase kernel (tuning / tests)
     int variant256;         // 8-phase kernel block rows: 0 auto, 3 -> 192, 4 -> 256
     int direct_store;       // 8-phase epilogue: 0 through LDS, 1 straight from the accumulator layout, 2 automatic
+    // EPI_MSDA only: output features [0, nsplit) come from W / bias and become sampling locations in Y (fp32, ldy),
+    // features [nsplit, N) come from W2 / bias2 and become the per-head softmax over L*P == 16 logits in Y2 (fp32, ldy2)
+    const uint16_t *W2 = nullptr, *bias2 = nullptr;
+    float *Y2 = nullptr;
+    const float *ref = nullptr;       // [M, mL, ref_dim] reference points
+    const int64_t *shapes = nullptr;  // [mL, 2] (H, W)
+    int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
 };
 
 int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
 int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio,
                                // bit3 asm tr-reads, bit4 no padding trim, 32 = automatic (default)
+int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);

@@ -34,7 +34,8 @@ bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda
 int msda_tiled6_launch_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                             const float *attw, int B, int S, int M, int L, int Lq, uint16_t *out, hipStream_t st);
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                      const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st);
+                      const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st,
+                      uint16_t *out16 = nullptr, int *wrote16 = nullptr);
 
 // ---------------------------------------------------------------------------------------------------------
 // Vectorised forward.
@@ -153,6 +154,9 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_fwd_vec_kernel(
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l];
             const int W = (int)shapes[2 * l + 1];
+            // an empty level: the reference accepts the point (h_im = -0.5 > -1) but every corner test fails, so it adds
+            // nothing and touches no memory -- the clamps below would otherwise produce index -1
+            if (H <= 0 || W <= 0) continue;
             const elem_t *vl = vb + (long)lsi[l] * MD;
 #pragma unroll
             for (int p = 0; p < np; ++p) {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(MSDA_BLOCK) void msda_bwd_vec_kernel(
         const long vb = (b * (long)S) * MD + (long)m * D + sub * 4;
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            if (H <= 0 || W <= 0) continue;   // empty level: no corner is inside, all gradients keep the caller's zero fill
             const long vl = vb + (long)lsi[l] * MD;
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
@@ -503,6 +508,22 @@ static int launch_generic_bwd(const T *value, const int64_t *shapes, const int64
 }  // namespace vllm
 
 using namespace vllm;
+
+namespace vllm {
+// The fp32 operator for a caller that consumes the result in bf16 (msda_layer.hip).  *where = 0: result in `out` (fp32);
+// 1: in `out16` when the level maps form a 2x pyramid, in `out` otherwise (the caller's conversion pass tests the same
+// device-side predicate, geometry_is_pyramid).
+int msda_forward_f32_out16(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                           int B, int S, int M, int D, int L, int Lq, int P, float *out, uint16_t *out16, int *where,
+                           hipStream_t st)
+{
+    *where = 0;
+    if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc) && (reinterpret_cast<uintptr_t>(out16) & 7u) == 0)
+        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, out16, where);
+    return vllm_msda_forward_f32(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, (vllm_stream_t)st);
+}
+}  // namespace vllm
 
 extern "C" int vllm_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                                      const float *loc, const float *attw, int B, int S, int M, int D, int L,

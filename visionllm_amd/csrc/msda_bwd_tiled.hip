@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
                 awp[p] = s_aw[slot * PT + kpt];
                 const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
                 him[p] = sp.h_im; wim[p] = sp.w_im; hlo[p] = sp.h_low; wlo[p] = sp.w_low;
-                okp[p] = (sp.ok && qok[p]) ? 1 : 0;
+                okp[p] = (sp.ok && qok[p] && H > 0 && W > 0) ? 1 : 0;   // (empty level: no corner inside, nothing to do)
                 if (okp[p]) {
                     const int h0 = min(max(sp.h_low, 0), H - 1), h1 = min(max(sp.h_low + 1, 0), H - 1);
                     const int x0 = min(max(sp.w_low, 0), W - 1), x1 = min(max(sp.w_low + 1, 0), W - 1);

@@ -9,10 +9,19 @@
 // Two elementwise kernels sit between the GEMMs and the operator:
 //   msda_prep_kernel   in place: offsets -> locations, logits -> softmax weights     (HBM-bound, one read + one write)
 //   f32_to_bf16_kernel operator output -> the bf16 operand of output_proj
+// Both disappear in the common case (L * P == 16, P even, H * L * P * 2 a multiple of 128 -- every detection head of the
+// reference): sampling_offsets and attention_weights become ONE GEMM over the queries whose epilogue (EPI_MSDA,
+// gemm_epilogue.hpp) does the softmax and the location arithmetic on the accumulator, and the LDS-tiled operator writes
+// bf16 itself.  The layer is then 4 launches: value GEMM, query GEMM, operator, output GEMM.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "msda_sample.hpp"
 
 namespace vllm {
+
+int msda_forward_f32_out16(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                           int B, int S, int M, int D, int L, int Lq, int P, float *out, uint16_t *out16, int *where,
+                           hipStream_t st);   // msda.hip
 
 namespace {
 
@@ -92,19 +101,25 @@ __global__ __launch_bounds__(256) void msda_prep_generic_kernel(float *__restric
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, long n4,
-                                                          long n)
+                                                          long n, const int64_t *__restrict__ shapes, int L, long Lq)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) {
+    // shapes != null: the operator already wrote bf16 for a pyramid geometry (msda_forward_f32_out16) -- nothing to do then.
+    // Grid-stride over a fixed grid, so that this "nothing" costs a couple of microseconds instead of 75 k empty blocks.
+    if (shapes && geometry_is_pyramid(shapes, L, Lq)) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4_t v = reinterpret_cast<const float4_t *>(src)[i];
         uint2_t o;
         o.x = pack_bf16x2(v[0], v[1]);
         o.y = pack_bf16x2(v[2], v[3]);
         reinterpret_cast<uint2_t *>(dst)[i] = o;
     }
-    if (i == 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
         for (long k = n4 * 4; k < n; ++k) dst[k] = f32_to_bf16(src[k]);
 }
+
+// msda_layer_fused = 0 (option / VLLM_MSDA_LAYER_FUSED): the round-1 composition (two query GEMMs + prep kernel + fp32
+// operator + conversion pass), kept as the A/B reference of the fused epilogue.
+inline bool layer_unfused() { return msda_layer_fused() == 0; }
 
 inline long align256(long x) { return (x + 255) & ~255L; }
 
@@ -147,12 +162,13 @@ int prep_launch(float *off, float *lg, const float *ref, const int64_t *shapes, 
     return VLLM_OK;
 }
 
-int cvt_launch(const float *src, uint16_t *dst, long n, hipStream_t st)
+int cvt_launch(const float *src, uint16_t *dst, long n, hipStream_t st, const int64_t *shapes = nullptr, int L = 0, long Lq = 0)
 {
     if (n == 0) return VLLM_OK;
     VLLM_REQUIRE(aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0, "f32_to_bf16: unaligned operands");
     const long n4 = n / 4;
-    VLLM_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)ceil_div(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, st, src, dst, n4, n);
+    const long blocks = ceil_div(n4 > 0 ? n4 : 1, 256);
+    VLLM_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, src, dst, n4, n, shapes, L, Lq);
     VLLM_CHECK_LAUNCH("f32_to_bf16_kernel");
     return VLLM_OK;
 }
@@ -228,16 +244,30 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D]
     TRY(gemm(st, EPI_F32, input_flatten, C, d->value_proj_w, C, d->value_proj_b, (uint16_t *)value, C, B * S, C, C, nullptr,
              (const uint16_t *)padding_mask));
-    // offsets / logits of the queries (:110-111) -- fp32 [B*Lq, M*L*P*2], [B*Lq, M*L*P]
-    TRY(gemm(st, EPI_F32, query, C, d->sampling_offsets_w, C, d->sampling_offsets_b, (uint16_t *)off, MLP * 2, B * Lq,
-             MLP * 2, C));
-    TRY(gemm(st, EPI_F32, query, C, d->attention_weights_w, C, d->attention_weights_b, (uint16_t *)lg, MLP, B * Lq, MLP, C));
-    // softmax + location arithmetic, in place (:112-129)
-    TRY(prep_launch(off, lg, ref, shapes, (long)B * Lq, M, L, P, d->ref_dim, d->use_4d_normalizer, st));
-    // the operator (:131-139), fp32
-    TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
+    if (L * P == 16 && P % 2 == 0 && (MLP * 2) % 128 == 0 && !layer_unfused()) {
+        // offsets and logits of the queries (:110-111) in one GEMM; softmax + location arithmetic (:112-129) in its epilogue
+        GemmArgs a;
+        a.X = query; a.W = d->sampling_offsets_w; a.Y = (uint16_t *)off; a.bias = d->sampling_offsets_b; a.scale = nullptr;
+        a.res = nullptr; a.M = B * Lq; a.N = MLP * 3; a.K = C; a.ldx = C; a.ldw = C; a.ldy = MLP * 2; a.ldr = 0; a.P = 0;
+        a.mt = a.nt = 0; a.xP = 0; a.variant = 1; a.variant256 = 0; a.direct_store = 0;
+        a.W2 = d->attention_weights_w; a.bias2 = d->attention_weights_b; a.Y2 = lg; a.ldy2 = MLP; a.nsplit = MLP * 2;
+        a.ref = ref; a.shapes = shapes; a.mL = L; a.mP = P; a.ref_dim = d->ref_dim; a.four_d = d->use_4d_normalizer;
+        TRY(gemm_bf16_launch(EPI_MSDA, a, st));
+    } else {
+        // offsets / logits of the queries (:110-111) -- fp32 [B*Lq, M*L*P*2], [B*Lq, M*L*P]
+        TRY(gemm(st, EPI_F32, query, C, d->sampling_offsets_w, C, d->sampling_offsets_b, (uint16_t *)off, MLP * 2, B * Lq,
+                 MLP * 2, C));
+        TRY(gemm(st, EPI_F32, query, C, d->attention_weights_w, C, d->attention_weights_b, (uint16_t *)lg, MLP, B * Lq, MLP,
+                 C));
+        // softmax + location arithmetic, in place (:112-129)
+        TRY(prep_launch(off, lg, ref, shapes, (long)B * Lq, M, L, P, d->ref_dim, d->use_4d_normalizer, st));
+    }
+    // the operator (:131-139), fp32 arithmetic; bf16 result straight from the LDS-tiled kernel where that one runs
+    int where = 0;
+    if (layer_unfused()) TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
+    else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st));
     // output_proj (:144)
-    TRY(cvt_launch(opout, opb, (long)B * Lq * C, st));
+    TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
     TRY(gemm(st, EPI_BIAS, opb, C, d->output_proj_w, C, d->output_proj_b, out, C, B * Lq, C, C));
     return VLLM_OK;
 }

@@ -63,7 +63,7 @@ __device__ __forceinline__ void gather_level_global(float (&acc)[Cfg::NPASS][4],
             const int hl = sp.h_low, wl = sp.w_low;
             const float lh = sp.h_im - (float)hl, lw = sp.w_im - (float)wl;
             const float hh = 1.f - lh, hw = 1.f - lw;
-            const bool pok = sp.ok && qok[p];
+            const bool pok = sp.ok && qok[p] && H > 0 && W > 0;
             const float w1 = pok ? hh * hw : 0.f, w2 = pok ? hh * lw : 0.f, w3 = pok ? lh * hw : 0.f, w4 = pok ? lh * lw : 0.f;
             const bool k1 = pok && hl >= 0 && wl >= 0;
             const bool k2 = pok && hl >= 0 && wl + 1 <= W - 1;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(MT_THREADS, Cfg::BPC) void msda_fwd_tiled_kernel(
                 awp[p] = s_aw[slot * PT + kpt];
                 const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
                 him[p] = sp.h_im; wim[p] = sp.w_im; hlo[p] = sp.h_low; wlo[p] = sp.w_low;
-                okp[p] = sp.ok && qok[p];
+                okp[p] = sp.ok && qok[p] && H > 0 && W > 0;   // (empty level: no corner inside, adds nothing)
                 if (okp[p]) {
                     const int h0 = min(max(sp.h_low, 0), H - 1), h1 = min(max(sp.h_low + 1, 0), H - 1);
                     const int x0 = min(max(sp.w_low, 0), W - 1), x1 = min(max(sp.w_low + 1, 0), W - 1);
@@ -326,7 +326,7 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                        hipStream_t st);   // msda_tiled4.hip
 bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
 int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st);   // msda_tiled7.hip
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16 = nullptr);   // msda_tiled7.hip
 int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, hipStream_t st);
 
@@ -339,13 +339,18 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
 // the generation-4 launch behind it skips pyramids, so exactly one of the two runs whatever the geometry, without a host
 // synchronisation.
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                      const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st)
+                      const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st, uint16_t *out16,
+                      int *wrote16)
 {
+    // out16 (optional): where a caller that wants the result in bf16 would like it.  *wrote16 = 1 tells it that a pyramid
+    // geometry's result went THERE (and `out` was left alone); any other geometry's result is in `out` as usual.
+    if (wrote16) *wrote16 = 0;
     const int mode = msda_tiled_enabled();
     // generations 4 / 6 keep pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
     if ((mode == 1 || mode == 15 || mode == 16) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
-        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st)) return e;
+        if (out16 && wrote16) *wrote16 = 1; else out16 = nullptr;
+        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16)) return e;
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
     }
     if (mode >= 10 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
 #pragma unroll
             for (int p = 0; p < NOWN; ++p) {
                 const SamplePoint<float> sp = sample_point<float>(lc[p].x, lc[p].y, H, W);
-                const bool ok = sp.ok && qok[p];
+                const bool ok = sp.ok && qok[p] && H > 0 && W > 0;   // (empty level: no corner inside, adds nothing)
                 hl[p] = sp.h_low; wl[p] = sp.w_low;
                 const float lh = sp.h_im - (float)sp.h_low, lw = sp.w_im - (float)sp.w_low;
                 const float hh = 1.f - lh, hw = 1.f - lw;

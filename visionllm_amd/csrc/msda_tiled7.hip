@@ -41,7 +41,7 @@ template <int NW, int WIN, bool PROF>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
-    float *__restrict__ out)
+    float *__restrict__ out, uint16_t *__restrict__ out16)
 {
     constexpr int D = 32, PT = 4, THREADS = NW * 64, QPP = NW * 8;
     static_assert(NW * 16 >= 170, "an item has up to 170 queries");
@@ -404,9 +404,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         T7_TICK(9)   // remaining DMA issue
         if (cv) {
             if (qokc) {
-                float *op = out + (size_t)prc * D;
-                store4(op + cA / 4, (float4_t){acc[0], acc[1], acc[2], acc[3]});
-                store4(op + (cA ^ 64) / 4, (float4_t){acc[4], acc[5], acc[6], acc[7]});
+                if (out16) {   // the caller (the fused layer) wants the bf16 operand of output_proj
+                    uint16_t *op = out16 + (size_t)prc * D;
+                    uint2_t o1, o2;
+                    o1.x = pack_bf16x2(acc[0], acc[1]); o1.y = pack_bf16x2(acc[2], acc[3]);
+                    o2.x = pack_bf16x2(acc[4], acc[5]); o2.y = pack_bf16x2(acc[6], acc[7]);
+                    *reinterpret_cast<uint2_t *>(op + cA / 4) = o1;
+                    *reinterpret_cast<uint2_t *>(op + (cA ^ 64) / 4) = o2;
+                } else {
+                    float *op = out + (size_t)prc * D;
+                    store4(op + cA / 4, (float4_t){acc[0], acc[1], acc[2], acc[3]});
+                    store4(op + (cA ^ 64) / 4, (float4_t){acc[4], acc[5], acc[6], acc[7]});
+                }
             }
             if (PROF) pacc[14] += 1;
         }
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
 
 template <int NW, int WIN, bool PROF>
 int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B, int S,
-          int M, int L, int Lq, float *out, hipStream_t st)
+          int M, int L, int Lq, float *out, uint16_t *out16, hipStream_t st)
 {
     static int cus = 0;
     if (cus == 0) {
@@ -446,7 +455,7 @@ int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
         attr_set = true;
     }
     VLLM_LAUNCH((msda_fwd_tiled7_kernel<NW, WIN, PROF>), dim3((cus / 8) * 8), dim3(NW * 64), lds, st, value, shapes, lsi, loc, attw,
-                B, S, M, L, Lq, out);
+                B, S, M, L, Lq, out, out16);
     VLLM_CHECK_LAUNCH("msda_fwd_tiled7_kernel");
     return VLLM_OK;
 }
@@ -454,10 +463,10 @@ int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
 }  // namespace
 
 int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st)
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16)
 {
-    if (prof) return t7_go<12, 1200, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
-    return t7_go<12, 1200, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
+    if (prof) return t7_go<12, 1200, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, st);
+    return t7_go<12, 1200, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, st);
 }
 
 int msda7_debug_counters(long *out, int n)

@@ -13,7 +13,15 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static int g_gemm_variant = -1, g_msda_tiled = -1, g_attn_variant = -1, g_gemm_direct = -1;
+static int g_gemm_variant = -1, g_msda_tiled = -1, g_attn_variant = -1, g_gemm_direct = -1, g_layer_fused = -1;
+int msda_layer_fused()
+{
+    if (g_layer_fused < 0) {   // 1 (default): query GEMM with the sampling epilogue + bf16 operator output; 0: round-1 composition
+        const char *e = getenv("VLLM_MSDA_LAYER_FUSED");
+        g_layer_fused = e ? (atoi(e) != 0) : 1;
+    }
+    return g_layer_fused;
+}
 int gemm_direct_store()
 {
     if (g_gemm_direct < 0) {   // 0 through LDS, 1 direct, 2 automatic (default)
@@ -63,6 +71,7 @@ extern "C" int vllm_set_option(const char *name, int value)
         vllm::g_msda_tiled = value;
         return old;
     }
+    if (!strcmp(name, "msda_layer_fused")) { const int old = vllm::msda_layer_fused(); vllm::g_layer_fused = value != 0; return old; }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 127; return old; }
     if (!strcmp(name, "gemm_variant")) {
