@@ -129,6 +129,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
         // 16-byte chunk c of row r lives at chunk c ^ (r & 15): conflict-free on the write side (16 rows per ds_write_b128
         // group) and on the read side (32 chunks of one row).
         float *ct = reinterpret_cast<float *>(smem);
+        const int c = lane & 31, n = n0 + c * 4;
+        const bool nok = n < a.N;
+        // EPI_MSDA (MSDeformAttn.forward ms_deform_attn.py:110-129 on the accumulator): per-lane constants of column n
+        // (the arithmetic below is msda_prep_kernel's, operation for operation: the two launch structures give the same bits)
+        const bool is_off = EPI == EPI_MSDA && n < a.nsplit;
+        int lvl = 0;
+        float Wl = 1.f, Hl = 1.f;
+        if (EPI == EPI_MSDA && is_off) {   // offsets in (head, level, point, xy) order: two points of level lvl
+            lvl = (n / (2 * a.mP)) % a.mL;
+            Wl = (float)a.shapes[2 * lvl + 1];
+            Hl = (float)a.shapes[2 * lvl];
+        }
+        // the reference points of this lane's 16 rows: issued before the transpose so their latency hides behind it
+        float4_t rp[16];
+        if (EPI == EPI_MSDA && is_off) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int m = m0 + p * 8 + wave * 2 + (lane >> 5);
+                const float *r = a.ref + ((size_t)(m < a.M ? m : a.M - 1) * a.mL + lvl) * a.ref_dim;
+                if (a.ref_dim == 2) { const float2_t t2 = *reinterpret_cast<const float2_t *>(r); rp[p] = (float4_t){t2.x, t2.y, 0.f, 0.f}; }
+                else rp[p] = *reinterpret_cast<const float4_t *>(r);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -137,22 +160,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
                 *reinterpret_cast<f32x4_t *>(ct + row * 128 + ((chunk ^ (row & 15)) << 2)) = acc[i][j];
             }
         __syncthreads();
-        const int c = lane & 31, n = n0 + c * 4;
-        const bool nok = n < a.N;
         const EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
-        // EPI_MSDA (MSDeformAttn.forward ms_deform_attn.py:110-129 on the accumulator): per-lane constants of column n
-        const bool is_off = EPI == EPI_MSDA && n < a.nsplit;
-        // (the arithmetic below is msda_prep_kernel's, operation for operation: the two launch structures give the same bits)
-        int lvl = 0;
-        float Wl = 1.f, Hl = 1.f;
-        if (EPI == EPI_MSDA && is_off) {   // offsets in (head, level, point, xy) order: two points of level lvl
-            lvl = (n / (2 * a.mP)) % a.mL;
-            Wl = (float)a.shapes[2 * lvl + 1];
-            Hl = (float)a.shapes[2 * lvl];
-        }
         const float invW = 1.f / Wl, invH = 1.f / Hl;
         const uint8_t *mask = EPI == EPI_F32 ? reinterpret_cast<const uint8_t *>(a.res) : nullptr;
-#pragma unroll 4
+#pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int row = p * 8 + wave * 2 + (lane >> 5);
             const int m = m0 + row;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
                 const float4_t o4 = {dead ? 0.f : v[0], dead ? 0.f : v[1], dead ? 0.f : v[2], dead ? 0.f : v[3]};
                 if (live) *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(a.Y) + (size_t)m * a.ldy + n) = o4;
             } else if (is_off) {
-                const float *r = a.ref + ((size_t)mc * a.mL + lvl) * a.ref_dim;
+                const float r[4] = {rp[p][0], rp[p][1], rp[p][2], rp[p][3]};
                 float sx, sy;
                 if (a.ref_dim == 2) { sx = invW; sy = invH; }
                 else if (a.four_d) { sx = r[2] * 0.5f / Wl; sy = r[3] * 0.5f / Hl; }
@@ -186,6 +197,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
                 const float4_t o4 = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
                 if (live) *reinterpret_cast<float4_t *>(a.Y2 + (size_t)m * a.ldy2 + (n - a.nsplit)) = o4;
             }
+        }
+        return;
+    }
+    if (!a.direct_store) {
+        // ---- bf16 epilogues, same route: row-wise from LDS a lane owns 8 consecutive features (one 16-byte store, 256
+        // contiguous bytes per row, 16-byte residual / position loads) instead of 8 bytes in each of 16 rows ----
+        float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + fr, chunk = wn * 16 + i * 4 + kq;
+                *reinterpret_cast<f32x4_t *>(ct + row * 128 + ((chunk ^ (row & 15)) << 2)) = acc[i][j];
+            }
+        __syncthreads();
+        const int c8 = lane & 15, n = n0 + c8 * 8;
+        if (n >= a.N) return;   // (N % 8 == 0 on this route; no barrier follows)
+        const EpiCols cols0 = epi_cols<EPI>(a, n), cols1 = epi_cols<EPI>(a, n + 4);
+#pragma unroll 4
+        for (int p = 0; p < 8; ++p) {
+            const int row = p * 16 + wave * 4 + (lane >> 4);
+            const int m = m0 + row;
+            if (m >= a.M) continue;
+            const f32x4_t t0 = *reinterpret_cast<const f32x4_t *>(ct + row * 128 + (((2 * c8) ^ (row & 15)) << 2));
+            const f32x4_t t1 = *reinterpret_cast<const f32x4_t *>(ct + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+            float v0[4], v1[4];
+            epi_value<EPI>(a, m, n, t0, cols0, v0);
+            epi_value<EPI>(a, m, n + 4, t1, cols1, v1);
+            uint4_t o;
+            o.x = pack_bf16x2(v0[0], v0[1]); o.y = pack_bf16x2(v0[2], v0[3]);
+            o.z = pack_bf16x2(v1[0], v1[1]); o.w = pack_bf16x2(v1[2], v1[3]);
+            *reinterpret_cast<uint4_t *>(a.Y + epi_out_row<EPI>(a, m) * a.ldy + n) = o;
         }
         return;
     }
@@ -220,7 +263,8 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     if (epi == EPI_MSDA) {
         VLLM_REQUIRE(a.W2 && a.Y2 && a.ref && a.shapes && a.mL > 0 && a.mP > 0 && a.mP % 2 == 0 && a.mL * a.mP == 16 &&
                          a.nsplit % BN == 0 && a.nsplit > 0 && a.nsplit < a.N && (a.N - a.nsplit) % 16 == 0 && a.ldy2 % 4 == 0 &&
-                         aligned16(a.W2) && aligned16(a.Y2) && aligned16(a.Y) && (a.ref_dim == 2 || a.ref_dim == 4),
+                         aligned16(a.W2) && aligned16(a.Y2) && aligned16(a.Y) && (a.ref_dim == 2 || a.ref_dim == 4) &&
+                         (reinterpret_cast<uintptr_t>(a.ref) & (a.ref_dim == 4 ? 15u : 7u)) == 0,
                      "gemm: bad operands for the MSDA sampling epilogue");
         a.variant = 1;
     }
@@ -228,6 +272,11 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");
     if (a.variant != 1 && (a.variant == 2 || (a.N >= 1024 && a.M >= 1024)))
         return gemm256_bf16_launch(epi, a, st);
+    // bf16 epilogues of this kernel: through LDS (0) when 16-byte rows are possible, else straight from the accumulators (1)
+    if (epi != EPI_F32 && epi != EPI_MSDA) {
+        const bool rows16 = a.N % 8 == 0 && a.ldy % 8 == 0 && aligned16(a.Y);
+        if (a.direct_store == 2 || a.direct_store == 0) a.direct_store = rows16 ? 0 : 1;
+    }
     a.mt = ceil_div(a.M, BM);
     a.nt = ceil_div(a.N, BN);
     long tiles;
