@@ -55,6 +55,43 @@ def test_forward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
     np.testing.assert_allclose(out.cpu().numpy(), tw, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,G,C,k,s,p,d,scale,sigma", [
+    (2, 56, 56, 4, 16, 3, 1, 1, 1, 1.0, 1.0),      # InternImage stage-1-like, group channels 16
+    (2, 42, 42, 5, 32, 3, 1, 1, 1, 1.0, 1.0),      # group channels 32 (bench shape family)
+    (1, 30, 41, 3, 32, 3, 2, 1, 1, 2.0, 1.5),      # strided, ragged map (partial tiles)
+    (1, 19, 21, 2, 16, 3, 1, 2, 2, 1.5, 1.0),      # dilation 2
+    (2, 11, 9, 2, 32, 1, 1, 0, 1, 1.0, 0.7),       # 1x1 kernel (one point per pixel)
+    (1, 20, 20, 2, 32, 2, 1, 0, 1, 1.0, 1.0),      # 2x2 kernel
+    (1, 40, 40, 2, 32, 3, 1, 1, 1, 1.0, 9.0),      # wide offsets: windows exceed the LDS budget -> global-memory tiles
+    (1, 40, 40, 2, 16, 3, 1, 1, 1, 1.0, 30.0),     # mostly rejected points
+])
+def test_tiled_kernel_vs_oracle_and_gather_kernel(N, H, W, G, C, k, s, p, d, scale, sigma):
+    """The LDS-tiled kernel (dcnv3_tiled.hip; fp32, group channels 16 / 32, <= 9 points) against the oracle and against the
+    gather kernel (option dcnv3_tiled = 0); two runs are bit-identical (race screen)."""
+    from visionllm_amd import _lib
+    rng = np.random.default_rng(H * 7 + C)
+    Ho, Wo = O.out_size(H, W, k, k, s, s, p, p, d, d)
+    inp = rng.standard_normal((N, H, W, G * C)).astype(np.float32)
+    off = (rng.standard_normal((N, Ho, Wo, G * k * k * 2)) * sigma).astype(np.float32)
+    off.reshape(-1)[3::101] = np.nan
+    off.reshape(-1)[5::103] = np.inf
+    msk = rng.random((N, Ho, Wo, G * k * k)).astype(np.float32)
+    a = (torch.from_numpy(inp).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(msk).to(DEV), k, k, s, s, p, p, d, d, G, C,
+         scale)
+    old = _lib.set_option("dcnv3_tiled", 1)
+    try:
+        out, again = A.dcnv3_forward(*a), A.dcnv3_forward(*a)
+        _lib.set_option("dcnv3_tiled", 0)
+        plain = A.dcnv3_forward(*a)
+    finally:
+        _lib.set_option("dcnv3_tiled", old)
+    assert torch.equal(out, again)
+    ref = O.forward(inp, off, msk, k, k, s, s, p, p, d, d, G, C, scale)
+    assert np.isfinite(ref).all()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(out, plain, rtol=1e-5, atol=1e-5)
+
+
 def test_nonfinite_data_and_locations_do_not_leak():
     N, H, W, G, C, k = 1, 6, 6, 2, 4, 3
     inp = torch.randn(N, H, W, G * C)

@@ -30,7 +30,7 @@ def main():
     for N, H, W, G, C in ((8, 336, 336, 10, 32), (8, 168, 168, 20, 32), (8, 84, 84, 40, 32), (8, 42, 42, 80, 32)):
         k = 3
         x = torch.randn(N, H, W, G * C, device=dev)
-        off = torch.randn(N, H, W, G * k * k * 2, device=dev)
+        off = torch.randn(N, H, W, G * k * k * 2, device=dev) * float(os.environ.get("DCN_OFFSET_SIGMA", "1.0"))
         m = torch.softmax(torch.randn(N, H, W, G, k * k, device=dev), -1).reshape(N, H, W, -1)
         sec = timeit(lambda: A.dcnv3_forward(x, off, m, k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0))
         algo = (x.numel() * 2 + off.numel() + m.numel()) * 4   # input + output + offsets + mask, fp32

@@ -8,18 +8,20 @@
 // read of the group's channels and the group's offsets / mask values are broadcast loads.  Corner loads are issued from
 // clamped addresses and selects decide what contributes (a NaN at a clamped address cannot leak).
 #include "common.hpp"
+#include "dcnv3_geo.hpp"
 
 namespace vllm {
+
+bool dcnv3_tiled_ok(const Dcnv3Geo &q, const float *in, const float *off, const float *msk, const float *out);   // dcnv3_tiled.hip
+int dcnv3_tiled_launch(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out,
+                       hipStream_t st);
+
 namespace {
 
 template <typename T> struct Opmath { typedef T type; };
 template <typename T> __device__ __forceinline__ T floor_t(T x);
 template <> __device__ __forceinline__ float floor_t<float>(float x) { return floorf(x); }
 template <> __device__ __forceinline__ double floor_t<double>(double x) { return floor(x); }
-
-struct Dcnv3Geo {
-    int N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
-};
 
 // K3 = true: 3x3 kernel, the 9-point loop is fully unrolled (36 independent corner loads per lane for the scheduler).
 template <typename T, int VEC, bool K3>
@@ -141,6 +143,8 @@ extern "C" int vllm_dcnv3_forward_f32(const float *input, const float *offset, c
     if (int e = make_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
     if (N == 0) return VLLM_OK;
     VLLM_REQUIRE(input && offset && mask && out, "dcnv3_forward_f32: null pointer");
+    if (dcnv3_tiled_ok(q, input, offset, mask, out))   // group channels 16 / 32, <= 9 points: the LDS-tiled kernel
+        return dcnv3_tiled_launch(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
     return dcnv3_launch<float>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
 }
 
