@@ -57,7 +57,8 @@ int vllm_device_info(char *name, int cap);
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */
 int vllm_set_option(const char *name, int value);
-/* Diagnostics: with "msda_tiled" = 5 / 10 / 14 / 16 the LDS-tiled MSDA kernel of that generation adds per-phase
+/* Diagnostics (VLLM_GEMM_PROF=1 in the environment: the 8-phase GEMM's prologue / main loop / epilogue ticks + block count;
+ * "dcnv3_tiled" = 2: the DCNv3 kernel's phases; otherwise:) with "msda_tiled" = 5 / 10 / 14 / 16 the LDS-tiled MSDA kernel of that generation adds per-phase
  * shader-clock ticks to 16 device counters; this reads the current generation's into out[0..n) and clears them.  Returns the
  * number of counters written. */
 int vllm_debug_counters(long *out, int n);

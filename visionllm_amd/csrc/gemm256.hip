@@ -15,6 +15,7 @@
 //     refilled while a lagging wave still reads it (WAR), and reads of a refilled half-tile start one phase after
 //     the vmcnt wait + barrier that retire it (RAW) -- /opt/skills/guides/cdna_hip_programming.md section 5.
 #include "common.hpp"
+#include <stdlib.h>
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
 
@@ -23,6 +24,7 @@ namespace vllm {
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+__device__ unsigned long long g_g2_prof[8];   // VLLM_GEMM_PROF: shader-clock ticks of wave 0 per phase, summed over blocks
 constexpr int G2_BN = 256, G2_BK = 64;   // block rows are 64 * MT (template parameter)
 constexpr int G2_THREADS = 512;
 constexpr int G2_HALF = 128 * G2_BK * 2;          // 16 KiB half-tile
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     }
     constexpr int BM_ = 64 * MT;                  // block rows: 2 halves x 2 wave rows x MT x 16
     const int m0 = tm_idx * BM_, n0 = tn_idx * G2_BN;
+    const unsigned t_start = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     const int nk = a.K / G2_BK;
 
     f32x4_t acc[MF32 ? 1 : 4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     issue_A(0, 1, 1); issue_B(1, 1, 1); issue_A(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     G2_BARRIER();
+    const unsigned t_pro = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     if (wr == 1) G2_BARRIER();   // stagger: group 1 runs one barrier behind group 0
 
     if constexpr (MF32) {
@@ -301,6 +305,18 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     }
     if (wr == 0) G2_BARRIER();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+    const unsigned t_loop = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    struct ProfEnd {
+        const GemmArgs &a; unsigned t0, t1, t2; int w, l;
+        __device__ ~ProfEnd() {
+            if (a.prof && w == 0 && l == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have been accepted by the memory system)
+                const unsigned t3 = (unsigned)__builtin_amdgcn_s_memtime();
+                atomicAdd(&g_g2_prof[0], (unsigned long long)(t1 - t0)); atomicAdd(&g_g2_prof[1], (unsigned long long)(t2 - t1));
+                atomicAdd(&g_g2_prof[2], (unsigned long long)(t3 - t2)); atomicAdd(&g_g2_prof[3], 1ull);
+            }
+        }
+    } prof_end{a, t_start, t_pro, t_loop, wave, lane};
 
     // ---- epilogue ----
     // bf16 outputs leave through LDS: the accumulator layout gives a wave store of 16 rows x 32 contiguous bytes
@@ -419,6 +435,7 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                   ? prop.multiProcessorCount : 256;
     }
     a.nt = ceil_div(a.N, G2_BN);
+    { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
     // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
     auto rounds_cost = [&](long rows, int mt_rows) {
@@ -463,6 +480,19 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 #undef L
     VLLM_CHECK_LAUNCH("gemm256_bf16_kernel");
     return VLLM_OK;
+}
+
+int gemm256_debug_counters(long *out, int n)
+{
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_g2_prof), sizeof(h)) != hipSuccess) {
+        set_error("gemm256_debug_counters: device read failed");
+        return VLLM_ELAUNCH;
+    }
+    for (int i = 0; i < n && i < 8; ++i) out[i] = (long)h[i];
+    const unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_g2_prof), z, sizeof(z));
+    return n < 8 ? n : 8;
 }
 
 }  // namespace vllm

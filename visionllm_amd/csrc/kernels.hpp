@@ -36,6 +36,7 @@ struct GemmArgs {
     const float *ref = nullptr;       // [M, mL, ref_dim] reference points
     const int64_t *shapes = nullptr;  // [mL, 2] (H, W)
     int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
+    int prof = 0;           // VLLM_GEMM_PROF=1: the 8-phase kernel adds prologue / main loop / epilogue ticks to device counters
 };
 
 int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")

@@ -94,10 +94,11 @@ extern "C" int vllm_set_option(const char *name, int value)
     vllm::set_error("unknown option %s", name);
     return VLLM_EINVAL;
 }
-namespace vllm { int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda7_debug_counters(long *out, int n); }
+namespace vllm { int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda7_debug_counters(long *out, int n); }
 extern "C" int vllm_debug_counters(long *out, int n)
 {
     if (!out || n <= 0) { vllm::set_error("vllm_debug_counters: bad arguments"); return VLLM_EINVAL; }
+    { static const int gp = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); if (gp) return vllm::gemm256_debug_counters(out, n); }
     if (vllm::dcnv3_tiled_enabled() == 2) return vllm::dcnv3_debug_counters(out, n);
     const int mode = vllm::msda_tiled_enabled();
     return mode >= 15 ? vllm::msda7_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
