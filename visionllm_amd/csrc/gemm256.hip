@@ -103,6 +103,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     constexpr int BM_ = 64 * MT;                  // block rows: 2 halves x 2 wave rows x MT x 16
     const int m0 = tm_idx * BM_, n0 = tn_idx * G2_BN;
     const unsigned t_start = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    const unsigned long long rt_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int nk = a.K / G2_BK;
 
     f32x4_t acc[MF32 ? 1 : 4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
@@ -307,8 +308,13 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
     const unsigned t_loop = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     struct ProfEnd {
-        const GemmArgs &a; unsigned t0, t1, t2; int w, l;
+        const GemmArgs &a; unsigned t0, t1, t2; int w, l; unsigned long long rt0;
         __device__ ~ProfEnd() {
+            if (a.trace && w == 0 && l == 0 && blockIdx.x < 8192) {
+                a.trace[blockIdx.x * 3 + 0] = rt0;
+                a.trace[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+                a.trace[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+            }
             if (a.prof && w == 0 && l == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have been accepted by the memory system)
                 const unsigned t3 = (unsigned)__builtin_amdgcn_s_memtime();
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 atomicAdd(&g_g2_prof[2], (unsigned long long)(t3 - t2)); atomicAdd(&g_g2_prof[3], 1ull);
             }
         }
-    } prof_end{a, t_start, t_pro, t_loop, wave, lane};
+    } prof_end{a, t_start, t_pro, t_loop, wave, lane, rt_start};
 
     // ---- epilogue ----
     // bf16 outputs leave through LDS: the accumulator layout gives a wave store of 16 rows x 32 contiguous bytes
@@ -436,6 +442,7 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     }
     a.nt = ceil_div(a.N, G2_BN);
     { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
+    { static unsigned long long *const tr = [] { const char *e = getenv("VLLM_GEMM_TRACE"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : (unsigned long long *)nullptr; }(); a.trace = tr; }
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
     // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
     auto rounds_cost = [&](long rows, int mt_rows) {

@@ -37,6 +37,8 @@ struct GemmArgs {
     const int64_t *shapes = nullptr;  // [mL, 2] (H, W)
     int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
     int prof = 0;           // VLLM_GEMM_PROF=1: the 8-phase kernel adds prologue / main loop / epilogue ticks to device counters
+    unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
+                                           // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
 };
 
 int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")
