@@ -36,6 +36,16 @@ void set_error(const char *fmt, ...);
         }                                                                              \
     } while (0)
 
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) is per DEVICE: a process that drives several GPUs must set it on each of them.
+// Returns true the first time it is called on the current device for the given mask (thread-safe).
+static inline bool first_use_on_device(unsigned long long *mask)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    const unsigned long long bit = 1ull << (d & 63);
+    const unsigned long long old = __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+    return !(old & bit);
+}
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -306,11 +306,10 @@ int dt_go(const float *in, const float *off, const float *msk, const Dcnv3Geo &q
     }
     constexpr size_t lds = 256 + (size_t)(WIN + 64 / (CPG / 4)) * CPG * 4 + (size_t)DT_NPX * DT_KMAX * 24 + 32;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_fwd_tiled_kernel<CPG, WIN, PROF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const long items = (long)q.N * q.G * ((q.Ho + DT_TH - 1) / DT_TH) * ((q.Wo + DT_TW - 1) / DT_TW);
     long blocks = (long)(cus / 8) * 8 * 2;

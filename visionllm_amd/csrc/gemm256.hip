@@ -463,14 +463,13 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     if (a.direct_store == 2) a.direct_store = 0;
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
     const size_t lds = 256 * 528;      // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
 #define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SETATTR(EPI_BIAS); SETATTR(EPI_GELU); SETATTR(EPI_QUICK_GELU); SETATTR(EPI_RESIDUAL); SETATTR(EPI_EMBED); SETATTR(EPI_F32);
 #undef SETATTR
-        attr_set = true;
     }
 #define L(E) do { if (mf32) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4, true>), grid, block, lds, st, a); \
                   else if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4>), grid, block, lds, st, a); \

@@ -275,11 +275,10 @@ int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BT_LDS);
-        attr_set = true;
     }
     const int grid = (cus / 8) * 8 * 3;   // persistent: 3 blocks per CU
     VLLM_LAUNCH(msda_bwd_tiled_kernel, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,

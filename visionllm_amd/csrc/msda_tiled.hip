@@ -308,11 +308,10 @@ static int tiled_launch_cfg(int cus, const float *value, const int64_t *shapes, 
                             const float *attw, int B, int S, int M, int L, int Lq, float *out, hipStream_t st)
 {
     const size_t lds = Cfg::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled_kernel<4, Cfg>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int grid = (cus / 8) * 8 * Cfg::BPC;   // persistent: BPC blocks per CU
     VLLM_LAUNCH((msda_fwd_tiled_kernel<4, Cfg>), dim3(grid), dim3(MT_THREADS), lds, st, value, shapes, lsi, loc, attw, B, S, M,

@@ -441,8 +441,8 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 8>),
@@ -451,7 +451,6 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 4, T4_WIN3, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)t4_lds(T4_WIN3));
-        attr_set = true;
     }
     const int mode = msda_tiled_enabled();
 #define T4_GO(PROF, NW, WIN, BPC)                                                                                     \

@@ -485,11 +485,10 @@ int t6_go(int cus, const VT *value, const int64_t *shapes, const int64_t *lsi, c
           int S, int M, int L, int Lq, OT *out, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(T6_ZPX + WIN + T6_SLACK) * 128 + 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC, PROF, GV, STG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     VLLM_LAUNCH((msda_fwd_tiled6_kernel<VT, OT, NW, NPASS, WIN, BPC, PROF, GV, STG>), dim3((cus / 8) * 8 * BPC), dim3(NW * 64), lds, st,
                 value, shapes, lsi, loc, attw, B, S, M, L, Lq, out);

@@ -448,11 +448,10 @@ int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
     }
     constexpr size_t lds = (size_t)(T6_ZPX + WIN + T6_SLACK) * 128 + 256;
     static_assert(lds <= 163840, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled7_kernel<NW, WIN, PROF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     VLLM_LAUNCH((msda_fwd_tiled7_kernel<NW, WIN, PROF>), dim3((cus / 8) * 8), dim3(NW * 64), lds, st, value, shapes, lsi, loc, attw,
                 B, S, M, L, Lq, out, out16);
