@@ -72,3 +72,24 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     from visionllm_amd.bridge import pixel_shuffle
     with pytest.raises(RuntimeError):
         pixel_shuffle(torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16))
+
+
+def test_level_pixels_is_remembered_per_tensor_object_and_version():
+    """ms_deform_attn.level_pixels: the reference's per-call `(shapes[:, 0] * shapes[:, 1]).sum() == Len_in` check, remembered
+    per tensor object + autograd version (one host synchronisation per forward pass instead of one per layer)."""
+    import torch
+    from visionllm_amd import ms_deform_attn as A
+    ss = torch.tensor([[3, 4], [2, 2]])
+    assert A.level_pixels(ss) == 16 and A.level_pixels(ss) == 16
+    ss[0, 0] = 5                                   # in-place change -> new version -> recomputed
+    assert A.level_pixels(ss) == 24
+    other = torch.tensor([[1, 1], [2, 2]])
+    assert A.level_pixels(other) == 5
+    del ss
+    fresh = torch.tensor([[7, 1], [1, 1]])         # (may reuse the id of the dead tensor: the weak reference catches it)
+    assert A.level_pixels(fresh) == 8
+    mod = A.MSDeformAttn(d_model=32, n_levels=2, n_heads=2, n_points=2)
+    q, src = torch.randn(1, 5, 32), torch.randn(1, 9, 32)
+    import pytest
+    with pytest.raises(AssertionError):            # the module's check still fires (ms_deform_attn.py:100)
+        mod(q, torch.rand(1, 5, 2, 2), src, fresh, torch.tensor([0, 7]), None)

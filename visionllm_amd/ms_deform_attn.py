@@ -20,6 +20,7 @@ would mask a broken kernel).
 import ctypes
 import math
 import warnings
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -245,12 +246,44 @@ def msda_layer_fused_ok(query, input_flatten, *linears, reference_points=None):
     return d_model % 64 == 0 and all(lin.weight.dtype == torch.bfloat16 and lin.bias is not None for lin in linears)
 
 
+_LEVEL_PIXELS = {}   # id(spatial_shapes) -> (weakref, tensor version, sum of H * W)
+
+
+def level_pixels(spatial_shapes):
+    """sum_l H_l * W_l of a [L, 2] shape tensor as a Python int -- the quantity the reference's modules compare with the value
+    length on every call (ms_deform_attn.py:100, multi_scale_deform_attn.py:319, ...mask_dn.py:741), which costs a host
+    synchronisation per layer.  The det heads pass the SAME tensor object to every encoder / decoder layer, so the result is
+    remembered per tensor object and autograd version (an in-place change bumps the version; a dead object's id can be
+    reused, hence the weak reference): one synchronisation per forward pass instead of one per layer, same check."""
+    key = id(spatial_shapes)
+    ent = _LEVEL_PIXELS.get(key)
+    if ent is not None and ent[0]() is spatial_shapes and ent[1] == spatial_shapes._version:
+        return ent[2]
+    total = int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum())
+    if len(_LEVEL_PIXELS) >= 64:
+        _LEVEL_PIXELS.clear()
+    _LEVEL_PIXELS[key] = (weakref.ref(spatial_shapes), spatial_shapes._version, total)
+    return total
+
+
 def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask,
                        value_proj, sampling_offsets, attention_weights, output_proj, n_heads, n_levels, n_points,
                        use_4d_normalizer=False):
     """value_proj -> offsets / weights linears -> softmax -> locations -> operator -> output_proj in ONE C call
     (vllm_msda_layer_forward; replaces ms_deform_attn.py:102-145 / ...mask_dn.py:729-782 for bf16 modules).
     query [B, Lq, C] bf16 (position embedding already added), reference_points [B, Lq, L, 2|4], input_flatten [B, S, C]."""
+    return msda_layer_prepare(query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask,
+                              value_proj, sampling_offsets, attention_weights, output_proj, n_heads, n_levels, n_points,
+                              use_4d_normalizer)()
+
+
+def msda_layer_prepare(query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask,
+                       value_proj, sampling_offsets, attention_weights, output_proj, n_heads, n_levels, n_points,
+                       use_4d_normalizer=False):
+    """Everything of msda_layer_forward that needs no device result -- argument checks, the descriptor, contiguous operands,
+    workspace, output -- and a zero-argument callable that enqueues the C call.  The module mirrors prepare FIRST and only
+    then evaluate the reference's `assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == Len_in` (a host
+    synchronisation): the host-side preparation then overlaps the GPU's backlog instead of sitting between two layers."""
     B, Lq, C = query.shape
     S = input_flatten.shape[1]
     if reference_points.shape[-1] not in (2, 4):
@@ -291,11 +324,15 @@ def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, l
         _lib.check(-1, "vllm_msda_layer_workspace_bytes")
     ws = _lib.workspace(q.device, nbytes)
     out = torch.empty_like(q)
-    with torch.cuda.device(q.device):
-        _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
-                                             _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
-                                             ws.numel(), _lib.current_stream(q.device)), "vllm_msda_layer_forward")
-    return out
+
+    def launch():
+        with torch.cuda.device(q.device):
+            _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
+                                                 _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
+                                                 ws.numel(), _lib.current_stream(q.device)), "vllm_msda_layer_forward")
+        launch.keep = keep   # (parameters referenced by the descriptor stay alive until the call has been enqueued)
+        return out
+    return launch
 
 
 def _msda_apply_fp32(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
@@ -337,13 +374,16 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        fused = None
         if msda_layer_fused_ok(query, input_flatten, self.value_proj, self.sampling_offsets, self.attention_weights,
                                self.output_proj, reference_points=reference_points):   # bf16 inference: one native call
-            return msda_layer_forward(query, reference_points, input_flatten, input_spatial_shapes,
-                                      input_level_start_index, input_padding_mask, self.value_proj,
-                                      self.sampling_offsets, self.attention_weights, self.output_proj, self.n_heads,
-                                      self.n_levels, self.n_points, self.use_4D_normalizer)
+            fused = msda_layer_prepare(query, reference_points, input_flatten, input_spatial_shapes,
+                                       input_level_start_index, input_padding_mask, self.value_proj,
+                                       self.sampling_offsets, self.attention_weights, self.output_proj, self.n_heads,
+                                       self.n_levels, self.n_points, self.use_4D_normalizer)
+        assert level_pixels(input_spatial_shapes) == Len_in
+        if fused is not None:
+            return fused()
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
@@ -401,13 +441,16 @@ class MultiScaleDeformableAttention(nn.Module):
             value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
-        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == num_value
+        fused = None
         if msda_layer_fused_ok(query, value, self.value_proj, self.sampling_offsets, self.attention_weights,
                                self.output_proj, reference_points=reference_points):
-            output = msda_layer_forward(query, reference_points, value, spatial_shapes, level_start_index,
-                                        key_padding_mask, self.value_proj, self.sampling_offsets,
-                                        self.attention_weights, self.output_proj, self.num_heads, self.num_levels,
-                                        self.num_points)
+            fused = msda_layer_prepare(query, reference_points, value, spatial_shapes, level_start_index,
+                                       key_padding_mask, self.value_proj, self.sampling_offsets,
+                                       self.attention_weights, self.output_proj, self.num_heads, self.num_levels,
+                                       self.num_points)
+        assert level_pixels(spatial_shapes) == num_value
+        if fused is not None:
+            output = fused()
             if not self.batch_first:
                 output = output.permute(1, 0, 2)
             return self.dropout(output) + identity
@@ -468,18 +511,20 @@ class GroundingDinoMultiscaleDeformableAttention(nn.Module):
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
         batch_size, num_queries, _ = hidden_states.shape
         batch_size, sequence_length, _ = encoder_hidden_states.shape
-        if (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() != sequence_length:
-            raise ValueError(
-                "Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
+        fused = None
         if not output_attentions and msda_layer_fused_ok(hidden_states, encoder_hidden_states, self.value_proj,
                                                          self.sampling_offsets, self.attention_weights,
                                                          self.output_proj, reference_points=reference_points):
             # (the attention weights stay inside the fused call; ask for output_attentions to get them)
-            output = msda_layer_forward(hidden_states, reference_points, encoder_hidden_states, spatial_shapes,
-                                        level_start_index, None if attention_mask is None else ~attention_mask,
-                                        self.value_proj, self.sampling_offsets, self.attention_weights,
-                                        self.output_proj, self.n_heads, self.n_levels, self.n_points)
-            return output, None
+            fused = msda_layer_prepare(hidden_states, reference_points, encoder_hidden_states, spatial_shapes,
+                                       level_start_index, None if attention_mask is None else ~attention_mask,
+                                       self.value_proj, self.sampling_offsets, self.attention_weights,
+                                       self.output_proj, self.n_heads, self.n_levels, self.n_points)
+        if level_pixels(spatial_shapes) != sequence_length:
+            raise ValueError(
+                "Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
+        if fused is not None:
+            return fused(), None
         value = self.value_proj(encoder_hidden_states)
         if attention_mask is not None:
             value = value.masked_fill(~attention_mask[..., None], float(0))
