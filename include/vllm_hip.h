@@ -47,8 +47,9 @@ int vllm_device_info(char *name, int cap);
  * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).
  * "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted
  * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).
- * "dcnv3_tiled": 1 (default) the LDS-tiled DCNv3 forward kernel for fp32, group channels 16 / 32, <= 9 points; 0 the gather
- * kernel (same results to fp32 rounding); 2 the tiled kernel with its phase clock (vllm_debug_counters then reads IT).
+ * "dcnv3_tiled": DCNv3 forward for fp32, group channels 16 / 32, <= 9 points: 1 (default) the pipelined LDS-tiled kernel
+ * (dcnv3_pipe.hip), 3 the two-blocks-per-CU LDS-tiled kernel (dcnv3_tiled.hip), 0 the gather kernel (same results to fp32
+ * rounding); 2 / 4 = 1 / 3 with the phase clock (vllm_debug_counters then reads IT).
  * "msda_layer_fused": 1 (default) vllm_msda_layer_forward runs sampling_offsets + attention_weights as one GEMM whose
  * epilogue does the softmax and the location arithmetic, and takes the operator's result in bf16 straight from the
  * LDS-tiled kernel (needs L * P == 16, P even; other layers compose automatically); 0 the explicit composition (two GEMMs,

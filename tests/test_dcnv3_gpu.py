@@ -64,10 +64,12 @@ def test_forward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
     (1, 20, 20, 2, 32, 2, 1, 0, 1, 1.0, 1.0),      # 2x2 kernel
     (1, 40, 40, 2, 32, 3, 1, 1, 1, 1.0, 9.0),      # wide offsets: windows exceed the LDS budget -> global-memory tiles
     (1, 40, 40, 2, 16, 3, 1, 1, 1, 1.0, 30.0),     # mostly rejected points
+    (2, 168, 168, 20, 32, 3, 1, 1, 1, 1.0, 1.0),   # bench shape: every block pipelines ~70 tiles
+    (1, 150, 90, 10, 16, 3, 1, 1, 1, 1.0, 2.0),    # several tiles per block, group channels 16, a mix of hot and cold tiles
 ])
 def test_tiled_kernel_vs_oracle_and_gather_kernel(N, H, W, G, C, k, s, p, d, scale, sigma):
-    """The LDS-tiled kernel (dcnv3_tiled.hip; fp32, group channels 16 / 32, <= 9 points) against the oracle and against the
-    gather kernel (option dcnv3_tiled = 0); two runs are bit-identical (race screen)."""
+    """The LDS-tiled kernels (dcnv3_pipe.hip / dcnv3_tiled.hip; fp32, group channels 16 / 32, <= 9 points) against the oracle and
+    against the gather kernel (option dcnv3_tiled = 0); two runs are bit-identical (race screen)."""
     from visionllm_amd import _lib
     rng = np.random.default_rng(H * 7 + C)
     Ho, Wo = O.out_size(H, W, k, k, s, s, p, p, d, d)
@@ -78,18 +80,21 @@ def test_tiled_kernel_vs_oracle_and_gather_kernel(N, H, W, G, C, k, s, p, d, sca
     msk = rng.random((N, Ho, Wo, G * k * k)).astype(np.float32)
     a = (torch.from_numpy(inp).to(DEV), torch.from_numpy(off).to(DEV), torch.from_numpy(msk).to(DEV), k, k, s, s, p, p, d, d, G, C,
          scale)
-    old = _lib.set_option("dcnv3_tiled", 1)
+    old = _lib.set_option("dcnv3_tiled", 0)
     try:
-        out, again = A.dcnv3_forward(*a), A.dcnv3_forward(*a)
-        _lib.set_option("dcnv3_tiled", 0)
         plain = A.dcnv3_forward(*a)
+        res = {}
+        for mode in (1, 3):   # 1: pipelined kernel (dcnv3_pipe.hip, default); 3: two-blocks-per-CU kernel (dcnv3_tiled.hip)
+            _lib.set_option("dcnv3_tiled", mode)
+            res[mode] = (A.dcnv3_forward(*a), A.dcnv3_forward(*a))
     finally:
         _lib.set_option("dcnv3_tiled", old)
-    assert torch.equal(out, again)
     ref = O.forward(inp, off, msk, k, k, s, s, p, p, d, d, G, C, scale)
     assert np.isfinite(ref).all()
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
-    torch.testing.assert_close(out, plain, rtol=1e-5, atol=1e-5)
+    for mode, (out, again) in res.items():
+        assert torch.equal(out, again), f"race: two runs of kernel variant {mode} differ"
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(out, plain, rtol=1e-5, atol=1e-5)
 
 
 def test_nonfinite_data_and_locations_do_not_leak():

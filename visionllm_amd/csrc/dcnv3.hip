@@ -15,6 +15,10 @@ namespace vllm {
 bool dcnv3_tiled_ok(const Dcnv3Geo &q, const float *in, const float *off, const float *msk, const float *out);   // dcnv3_tiled.hip
 int dcnv3_tiled_launch(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out,
                        hipStream_t st);
+bool dcnv3_pipe_ok(const Dcnv3Geo &q);                                                                           // dcnv3_pipe.hip
+int dcnv3_pipe_launch(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out, int prof,
+                      hipStream_t st);
+int dcnv3_tiled_enabled();   // runtime.cpp: 0 gather kernel, 1 pipelined tiled kernel (2: + phase clock), 3 two-block tiled kernel (4: + phase clock)
 
 namespace {
 
@@ -143,8 +147,11 @@ extern "C" int vllm_dcnv3_forward_f32(const float *input, const float *offset, c
     if (int e = make_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
     if (N == 0) return VLLM_OK;
     VLLM_REQUIRE(input && offset && mask && out, "dcnv3_forward_f32: null pointer");
-    if (dcnv3_tiled_ok(q, input, offset, mask, out))   // group channels 16 / 32, <= 9 points: the LDS-tiled kernel
+    if (dcnv3_tiled_ok(q, input, offset, mask, out)) {   // group channels 16 / 32, <= 9 points: the LDS-tiled kernels
+        const int mode = dcnv3_tiled_enabled();
+        if (mode <= 2 && dcnv3_pipe_ok(q)) return dcnv3_pipe_launch(input, offset, mask, q, offset_scale, out, mode == 2, (hipStream_t)stream);
         return dcnv3_tiled_launch(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
+    }
     return dcnv3_launch<float>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
 }
 

@@ -333,7 +333,7 @@ int dcnv3_tiled_launch(const float *in, const float *off, const float *msk, cons
                        hipStream_t st)
 {
     if ((long)q.N * q.Ho * q.Wo * q.G == 0) return VLLM_OK;
-    const bool prof = dcnv3_tiled_enabled() == 2;
+    const bool prof = dcnv3_tiled_enabled() == 4;
     if (q.C == 32) return prof ? dt_go<32, 500, true>(in, off, msk, q, offset_scale, out, st) : dt_go<32, 500, false>(in, off, msk, q, offset_scale, out, st);
     return prof ? dt_go<16, 1000, true>(in, off, msk, q, offset_scale, out, st) : dt_go<16, 1000, false>(in, off, msk, q, offset_scale, out, st);
 }

@@ -20,7 +20,7 @@ int dcnv3_tiled_enabled()
     if (g_dcnv3_tiled < 0) {   // 1 (default): LDS-tiled DCNv3 forward where it applies; 0: the gather kernel
         const char *e = getenv("VLLM_DCNV3_TILED");
         g_dcnv3_tiled = e ? atoi(e) : 1;
-        if (g_dcnv3_tiled < 0 || g_dcnv3_tiled > 2) g_dcnv3_tiled = 1;
+        if (g_dcnv3_tiled < 0 || g_dcnv3_tiled > 4) g_dcnv3_tiled = 1;
     }
     return g_dcnv3_tiled;
 }
@@ -81,7 +81,7 @@ extern "C" int vllm_set_option(const char *name, int value)
         vllm::g_msda_tiled = value;
         return old;
     }
-    if (!strcmp(name, "dcnv3_tiled")) { const int old = vllm::dcnv3_tiled_enabled(); vllm::g_dcnv3_tiled = (value < 0 || value > 2) ? 1 : value; return old; }
+    if (!strcmp(name, "dcnv3_tiled")) { const int old = vllm::dcnv3_tiled_enabled(); vllm::g_dcnv3_tiled = (value < 0 || value > 4) ? 1 : value; return old; }
     if (!strcmp(name, "msda_layer_fused")) { const int old = vllm::msda_layer_fused(); vllm::g_layer_fused = value != 0; return old; }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 127; return old; }
@@ -94,12 +94,13 @@ extern "C" int vllm_set_option(const char *name, int value)
     vllm::set_error("unknown option %s", name);
     return VLLM_EINVAL;
 }
-namespace vllm { int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda7_debug_counters(long *out, int n); }
+namespace vllm { int dcnv3_pipe_debug_counters(long *out, int n); int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda7_debug_counters(long *out, int n); }
 extern "C" int vllm_debug_counters(long *out, int n)
 {
     if (!out || n <= 0) { vllm::set_error("vllm_debug_counters: bad arguments"); return VLLM_EINVAL; }
     { static const int gp = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); if (gp) return vllm::gemm256_debug_counters(out, n); }
-    if (vllm::dcnv3_tiled_enabled() == 2) return vllm::dcnv3_debug_counters(out, n);
+    if (vllm::dcnv3_tiled_enabled() == 2) return vllm::dcnv3_pipe_debug_counters(out, n);
+    if (vllm::dcnv3_tiled_enabled() == 4) return vllm::dcnv3_debug_counters(out, n);
     const int mode = vllm::msda_tiled_enabled();
     return mode >= 15 ? vllm::msda7_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
 }
