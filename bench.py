@@ -291,6 +291,10 @@ def main():
     ap.add_argument("--msda-stream", type=int, default=0, choices=[0, 1],
                     help="0 (default): one stream; 1: the MSDA calls on a side stream next to the ViT (cross-batch pipelining: in "
                          "the reference the det head of a batch depends on that batch's LLM output)")
+    ap.add_argument("--allgather-lag", type=int, default=1, choices=[0, 1],
+                    help="N > 1: 1 (default) = a step's token all-gather is waited for one step later, so it overlaps the next "
+                         "step's encoder too (steady-state pipeline; everything is drained inside the timed region); 0 = waited "
+                         "for at the end of its own step")
     ap.add_argument("--allgather", default="collective", choices=["collective", "direct"],
                     help="token all-gather: RCCL all_gather_into_tensor (default) or batched point-to-point to all peers at once")
     ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
@@ -359,7 +363,13 @@ def main():
         if side is None:
             msda_calls(res)
         if marks is None:
-            gathered, _ = handle.wait()
+            if args.allgather_lag and world > 1:
+                # software pipeline across steps: this step's collective is waited for one step later (before the next one is
+                # launched), so it overlaps the NEXT step's encoder as well; the last one is drained before the timed region ends
+                prev, pending[0] = pending[0], handle
+                gathered = prev.wait()[0] if prev is not None else None
+            else:
+                gathered, _ = handle.wait()
         if side is not None:
             main.wait_stream(side)
         if marks is not None:
@@ -367,9 +377,17 @@ def main():
         res.append(gathered)
         return res
 
+    pending = [None]
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -377,6 +395,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        drain()                      # (the last step's collective belongs to the timed region)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -425,7 +444,7 @@ def main():
                        "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096",
                        "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
                        "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else ""),
-                       "rccl_ranks": world, "allgather": args.allgather,
+                       "rccl_ranks": world, "allgather": args.allgather, "allgather_lag_steps": args.allgather_lag if world > 1 else 0,
                        "streams": ("vit+projector | msda (side stream; cross-batch pipelining)" if args.msda_stream else "single") +
                                   ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
             "phases_ms": {"vit_projector": float(red[1].item()), "token_allgather": float(red[2].item()), "msda_12_calls": float(red[3].item()),

@@ -42,6 +42,19 @@ def _worker(rank, world, port, ragged, q):
     out3, counts3 = all_gather_visual_tokens(tok, algo="direct")
     out4, _ = all_gather_visual_tokens(tok, counts=counts, async_op=True, algo="direct").wait()
     assert counts3 == counts and torch.equal(out3, out) and torch.equal(out4, out)
+    # the bench's pipeline across steps: a step's collective is waited for one step later, the last one is drained at the end;
+    # several collectives may be in flight and every one must deliver ITS step's tokens
+    for algo in ("collective", "direct"):
+        pending, got = None, []
+        for stepi in range(4):
+            t = tok + stepi
+            h = all_gather_visual_tokens(t, counts=counts, async_op=True, algo=algo)
+            prev, pending = pending, h
+            if prev is not None:
+                got.append(prev.wait()[0])
+        got.append(pending.wait()[0])
+        for stepi, g in enumerate(got):
+            assert torch.equal(g, (out.float() + stepi).to(torch.bfloat16)), (algo, stepi)
     q.put((rank, out.float(), counts))
     dist.destroy_process_group()
 
