@@ -202,10 +202,10 @@ def cpu_baseline(ivit=False):
     """The reference's CPU path on the host cores of this box, bounded sample, extrapolated to images/sec.
 
     vitl: transformers.CLIPVisionModel (the class the reference instantiates, modeling_visionllmv2.py:135; eager attention,
-    fp32) on ONE 336^2 tile + the mlp2x_gelu bridge (oracle restatement of :174-182) + the reference's pure-torch MSDA
+    fp32) on the 5 tiles of ONE image + the mlp2x_gelu bridge (oracle restatement of :174-182) + the reference's pure-torch MSDA
     twin (oracle restatement of multi_scale_deform_attn.py:100-159, pinned to reference-run fixtures) at B=1 for the
     encoder and decoder shapes.  internvit6b: the InternViT restatement (oracle/vit.py, pinned to the reference class's
-    fixtures) at 2 of 48 layers, one tile, extrapolated x24 (stated in `sample`)."""
+    fixtures) at 2 of 48 layers on the 5 tiles, extrapolated x24 (stated in `sample`).  ~10-25 s of CPU work."""
     from msda_inputs import make_inputs
     from oracle import msda as OM
     from oracle import vit as OV
@@ -218,7 +218,7 @@ def cpu_baseline(ivit=False):
         if not ivit:
             from transformers import CLIPVisionConfig, CLIPVisionModel
             model = CLIPVisionModel(CLIPVisionConfig(**VIT, attn_implementation="eager")).eval()
-            x = torch.randn(1, 3, 336, 336)
+            x = torch.randn(TILES_PER_IMAGE, 3, 336, 336)   # the 5 tiles of ONE 1336^2 image
             hs = [None]
 
             def run_vit():
@@ -228,8 +228,8 @@ def cpu_baseline(ivit=False):
             bsd = {"0.weight": torch.randn(LLM_HIDDEN, C) * 0.02, "0.bias": torch.zeros(LLM_HIDDEN),
                    "2.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "2.bias": torch.zeros(LLM_HIDDEN)}
             t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "mlp2x_gelu", hs[0][-2][:, 1:]))
-            vit_note = (f"transformers {__import__('transformers').__version__} CLIPVisionModel ViT-L/14-336 fp32 eager, 1 tile x 24 "
-                        f"layers ({t_vit:.2f}s) + mlp2x_gelu bridge 1 tile ({t_bridge:.2f}s)")
+            vit_note = (f"transformers {__import__('transformers').__version__} CLIPVisionModel ViT-L/14-336 fp32 eager, the 5 tiles of one "
+                        f"image x 24 layers ({t_vit:.2f}s) + mlp2x_gelu bridge on them ({t_bridge:.2f}s)")
         else:
             cfg = dict(IVIT, num_hidden_layers=2)
             C, I = IVIT["hidden_size"], IVIT["intermediate_size"]
@@ -244,26 +244,26 @@ def cpu_baseline(ivit=False):
                            pfx + "mlp.fc1.bias": torch.zeros(I), pfx + "mlp.fc2.weight": torch.randn(C, I) * 0.02,
                            pfx + "mlp.fc2.bias": torch.zeros(C), pfx + "norm1.weight": torch.ones(C), pfx + "norm2.weight": torch.ones(C),
                            pfx + "ls1": torch.full((C,), 0.1), pfx + "ls2": torch.full((C,), 0.1)})
-            x = torch.randn(1, 3, 448, 448)
+            x = torch.randn(TILES_PER_IMAGE, 3, 448, 448)   # the 5 tiles of ONE image
             t2 = _median_time(lambda: OV.intern_vit_forward(sd, cfg, x))
             t_vit = t2 * (IVIT["num_hidden_layers"] / 2)
             bsd = {"0.weight": torch.ones(4 * C), "0.bias": torch.zeros(4 * C), "1.weight": torch.randn(LLM_HIDDEN, 4 * C) * 0.02,
                    "1.bias": torch.zeros(LLM_HIDDEN), "3.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "3.bias": torch.zeros(LLM_HIDDEN)}
-            feats = OV.select_features([torch.randn(1, S, C)] * 2, -2, True)
+            feats = OV.select_features([torch.randn(TILES_PER_IMAGE, S, C)] * 2, -2, True)
             t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "internvl_mlp", feats))
-            vit_note = (f"InternViT-6B restatement (oracle/vit.py) fp32, 1 tile of 448^2 x 2 of 48 layers ({t2:.2f}s), EXTRAPOLATED x24 = "
-                        f"{t_vit:.1f}s + pixel-shuffle + internvl_mlp bridge 1 tile ({t_bridge:.2f}s)")
+            vit_note = (f"InternViT-6B restatement (oracle/vit.py) fp32, the 5 tiles (448^2) of one image x 2 of 48 layers ({t2:.2f}s), "
+                        f"EXTRAPOLATED x24 = {t_vit:.1f}s + pixel-shuffle + internvl_mlp bridge on them ({t_bridge:.2f}s)")
         g = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], mode="encoder_like", seed=0)
         tv, tl, tw = torch.from_numpy(g["value"]), torch.from_numpy(g["loc"]), torch.from_numpy(g["attw"])
         t_msda_enc = _median_time(lambda: OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw))
         gd = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], Lq=MSDA["dec_queries"], mode="encoder_like", seed=1)
         dv, dl, dw = torch.from_numpy(gd["value"]), torch.from_numpy(gd["loc"]), torch.from_numpy(gd["attw"])
         t_msda_dec = _median_time(lambda: OM.grid_sample_twin(dv, gd["shapes"].tolist(), dl, dw))
-    t_image = TILES_PER_IMAGE * (t_vit + t_bridge) + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
+    t_image = t_vit + t_bridge + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
     return dict(value=1.0 / t_image, unit="images/sec", cores=threads, kind="port",
                 sample=(f"{threads} host threads, 1 warm-up + 3 repetitions each, median: {vit_note} + reference grid_sample MSDA twin B=1 "
-                        f"Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 ({t_msda_dec:.2f}s); image = 5 tiles + 6 enc + 6 dec MSDA calls "
-                        f"(B=1 each; B=8 calls are 8x these), extrapolated from this one-tile / one-call sample"))
+                        f"Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 ({t_msda_dec:.2f}s); sample = ONE image: its 5 tiles in one batch + 6 encoder-shaped + 6 "
+                        f"decoder-shaped MSDA calls at B=1 (one call of each shape timed, x6)"))
 
 
 def _respawn_under_launcher(n):
