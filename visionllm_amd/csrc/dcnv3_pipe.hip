@@ -265,101 +265,203 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
 
         // ---- gather cur (window of cur, DPP broadcasts from the owner lane of each point) ----
         if (cv) {
-            float acc[NR][4];
+            if constexpr (CPG == 32) {
+                // PAIR gather -- bank-conflict-free whatever the pixels are.  A ds_read_b128 is served in groups of 16 lanes = 4
+                // quads = 4 unrelated pixels; a 128-byte pixel row is half of the 64 banks, so quads reading 64 contiguous bytes of
+                // ONE pixel collide whenever their pixels have equal bank parity (2-4 LDS cycles per group, and the LDS pipe is what
+                // bounds this gather: 590 KB per tile).  Here lanes (0,1) of a quad read a 32-byte piece of the LEFT pixel of the 2x2
+                // footprint and lanes (2,3) the same piece of the RIGHT pixel -- horizontal neighbours have opposite parity, so a
+                // quad always covers 8 banks of each half at the position of its piece -- and the 4 quads of a lane group read 4
+                // different pieces (rank ^ t, rank = the quad's number in its group {0,3,5,6} / {1,2,4,7} = quad >> 1): 64 distinct
+                // banks, every read.  A lane owns 16 channels of ONE column (two weights per point); the columns are added before
+                // the store.
+                const int pr_p = lane & 1, pr_s = (lane >> 1) & 1, pr_rank = (lane >> 3) & 3;
+                float acc[4][4];   // [read t][channel 8 * (rank ^ t) + 4 p + c]
 #pragma unroll
-            for (int h = 0; h < NR; ++h)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[h][c] = 0.f;
-            if (cur_hot) {
-                const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char *)smem + so;
+                    for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+                if (cur_hot) {
+                    const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char *)smem + pr_s * 128 + pr_rank * 32 + pr_p * 16;
 #define DP_POINT(R_, LQ)                                                                                          \
-    if (LQ + 4 * R_ < K && !(DP_ABLATE & 2)) {                                                                                        \
-        const int t0 = dp_qbi<LQ>(pc.top[R_]) + lbase, t1 = dp_qbi<LQ>(pc.bot[R_]) + lbase;                       \
-        float4_t a1, a2, a3, a4, c1, c2, c3, c4;                                                                  \
-        /* the reads are ISSUED here and WAITED for after the DMA round: the round's address arithmetic and the issue stall */ \
-        /* of its global_load_lds hide behind the LDS round trip.  The destination registers are named again only by the   */ \
-        /* waiting statement, so the compiler has no reason to touch them in between.                                      */ \
-        if constexpr (NR == 2) {                                                                                  \
-            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:128\n\t"                              \
-                         "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:128\n\t"                              \
-                         "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:192\n\t"                    \
-                         "ds_read_b128 %6, %9 offset:64\n\tds_read_b128 %7, %9 offset:192"                         \
-                         : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4) \
-                         : "v"(t0), "v"(t1) : "memory");                                                          \
-        } else {                                                                                                  \
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\t"                               \
-                         "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"                                   \
-                         : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4) : "v"(t0), "v"(t1) : "memory");             \
-            c1 = c2 = c3 = c4 = (float4_t){0.f, 0.f, 0.f, 0.f};                                                   \
-        }                                                                                                         \
+    if (LQ + 4 * R_ < K && !(DP_ABLATE & 2)) {                                                                    \
+        const int t0 = dp_qbi<LQ>(pc.top[R_]) + lbase, t1 = t0 ^ 32, t2 = t0 ^ 64, t3 = t0 ^ 96;                  \
+        const int b0 = dp_qbi<LQ>(pc.bot[R_]) + lbase, b1 = b0 ^ 32, b2 = b0 ^ 64, b3 = b0 ^ 96;                  \
+        float4_t a0, a1, a2, a3, c0, c1, c2, c3;                                                                  \
+        /* reads ISSUED here, WAITED for after the DMA round (its address arithmetic and issue stall hide behind the LDS */ \
+        /* round trip); the destination registers are named again only by the waiting statement                          */ \
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"   \
+                     "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"      \
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)     \
+                     : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");        \
         dma_round();                                                                                              \
-        if constexpr (NR == 2) {                                                                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4) : : "memory"); \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : "memory");           \
-        }                                                                                                         \
-        const float e1 = dp_qbf<LQ>(pc.w1[R_]), e2 = dp_qbf<LQ>(pc.w2[R_]), e3 = dp_qbf<LQ>(pc.w3[R_]),           \
-                    e4 = dp_qbf<LQ>(pc.w4[R_]);                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory"); \
+        const float x1 = dp_qbf<LQ>(pc.w1[R_]), x2 = dp_qbf<LQ>(pc.w2[R_]), x3 = dp_qbf<LQ>(pc.w3[R_]),           \
+                    x4 = dp_qbf<LQ>(pc.w4[R_]);                                                                   \
+        const float eT = pr_s ? x2 : x1, eB = pr_s ? x4 : x3;                                                     \
         _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                        \
-            float2_t t = {acc[0][c], acc[0][c + 1]};                                                              \
-            t = dp_fma2(e1, (float2_t){a1[c], a1[c + 1]}, t); t = dp_fma2(e2, (float2_t){a2[c], a2[c + 1]}, t);   \
-            t = dp_fma2(e3, (float2_t){a3[c], a3[c + 1]}, t); t = dp_fma2(e4, (float2_t){a4[c], a4[c + 1]}, t);   \
-            acc[0][c] = t.x; acc[0][c + 1] = t.y;                                                                 \
-            if constexpr (NR == 2) {                                                                              \
-                float2_t u = {acc[NR - 1][c], acc[NR - 1][c + 1]};                                                \
-                u = dp_fma2(e1, (float2_t){c1[c], c1[c + 1]}, u); u = dp_fma2(e2, (float2_t){c2[c], c2[c + 1]}, u); \
-                u = dp_fma2(e3, (float2_t){c3[c], c3[c + 1]}, u); u = dp_fma2(e4, (float2_t){c4[c], c4[c + 1]}, u); \
-                acc[NR - 1][c] = u.x; acc[NR - 1][c + 1] = u.y;                                                   \
-            }                                                                                                     \
+            float2_t u0 = {acc[0][c], acc[0][c + 1]}, u1 = {acc[1][c], acc[1][c + 1]};                            \
+            float2_t u2 = {acc[2][c], acc[2][c + 1]}, u3 = {acc[3][c], acc[3][c + 1]};                            \
+            u0 = dp_fma2(eT, (float2_t){a0[c], a0[c + 1]}, u0); u0 = dp_fma2(eB, (float2_t){c0[c], c0[c + 1]}, u0); \
+            u1 = dp_fma2(eT, (float2_t){a1[c], a1[c + 1]}, u1); u1 = dp_fma2(eB, (float2_t){c1[c], c1[c + 1]}, u1); \
+            u2 = dp_fma2(eT, (float2_t){a2[c], a2[c + 1]}, u2); u2 = dp_fma2(eB, (float2_t){c2[c], c2[c + 1]}, u2); \
+            u3 = dp_fma2(eT, (float2_t){a3[c], a3[c + 1]}, u3); u3 = dp_fma2(eB, (float2_t){c3[c], c3[c + 1]}, u3); \
+            acc[0][c] = u0.x; acc[0][c + 1] = u0.y; acc[1][c] = u1.x; acc[1][c + 1] = u1.y;                        \
+            acc[2][c] = u2.x; acc[2][c + 1] = u2.y; acc[3][c] = u3.x; acc[3][c + 1] = u3.y;                        \
         }                                                                                                         \
         /* pin the sums: otherwise the multiply-adds sink below the DMA round's branch and the loads are spilled */ \
-        _Pragma("unroll") for (int h = 0; h < NR; ++h)                                                            \
-            asm volatile("" : "+v"(acc[h][0]), "+v"(acc[h][1]), "+v"(acc[h][2]), "+v"(acc[h][3]));                \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                             \
+            asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]), "+v"(acc[t][2]), "+v"(acc[t][3]));                \
     } else {                                                                                                      \
         dma_round();                                                                                              \
     }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
-                // (the +128 / +192 immediates are the right-hand pixel of the corner pair: PXB = 128 for 32 channels; for 16
-                // channels a pixel is 64 bytes and the pair's second pixel sits at +64)
-                DP_POINT(0, 0) DP_POINT(0, 1) DP_POINT(0, 2) DP_POINT(0, 3)
-                DP_POINT(1, 0) DP_POINT(1, 1) DP_POINT(1, 2) DP_POINT(1, 3)
-                DP_POINT(2, 0)
+                    DP_POINT(0, 0) DP_POINT(0, 1) DP_POINT(0, 2) DP_POINT(0, 3)
+                    DP_POINT(1, 0) DP_POINT(1, 1) DP_POINT(1, 2) DP_POINT(1, 3)
+                    DP_POINT(2, 0)
 #undef DP_POINT
-            } else {
-                // cold tile: corners from global memory (clamped addresses, selects decide what contributes)
-                const float *slab = in + (long)cur.b * q.H * q.W * GC + (long)cur.g * CPG + k * 4;
-                for (int p = 0; p < K; ++p) {
-                    const int src = ((lane & ~3) | (p & 3)) << 2, r = p >> 2;
-                    const int tb_x = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.top[0] : r == 1 ? pc.top[1] : pc.top[2]);
-                    const int tb_y = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.bot[0] : r == 1 ? pc.bot[1] : pc.bot[2]);
-                    float w[4];
-                    w[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w1[0] : r == 1 ? pc.w1[1] : pc.w1[2])));
-                    w[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w2[0] : r == 1 ? pc.w2[1] : pc.w2[2])));
-                    w[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w3[0] : r == 1 ? pc.w3[1] : pc.w3[2])));
-                    w[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w4[0] : r == 1 ? pc.w4[1] : pc.w4[2])));
-                    const int h = tb_x, wl_ = tb_y;
-                    const bool u0 = h >= 0, u1 = h + 1 >= 0 && h + 1 <= q.H - 1, l0 = wl_ >= 0, l1 = wl_ + 1 >= 0 && wl_ + 1 <= q.W - 1;
-                    const int ya = min(max(h, 0), q.H - 1), yb = min(max(h + 1, 0), q.H - 1);
-                    const int xa = min(max(wl_, 0), q.W - 1), xb = min(max(wl_ + 1, 0), q.W - 1);
+                } else {
+                    // cold tile: this lane's column of the footprint from global memory (clamped addresses, selects decide what
+                    // contributes)
+                    const float *slab = in + (long)cur.b * q.H * q.W * GC + (long)cur.g * CPG + pr_p * 4;
+                    for (int p = 0; p < K; ++p) {
+                        const int src = ((lane & ~3) | (p & 3)) << 2, r = p >> 2;
+                        const int h = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.top[0] : r == 1 ? pc.top[1] : pc.top[2]);
+                        const int wl_ = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.bot[0] : r == 1 ? pc.bot[1] : pc.bot[2]);
+                        // the owner's weights of BOTH columns (the receiver picks its own column)
+                        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w1[0] : r == 1 ? pc.w1[1] : pc.w1[2])));
+                        const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w2[0] : r == 1 ? pc.w2[1] : pc.w2[2])));
+                        const float o3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w3[0] : r == 1 ? pc.w3[1] : pc.w3[2])));
+                        const float o4 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w4[0] : r == 1 ? pc.w4[1] : pc.w4[2])));
+                        const float eT = pr_s ? o2 : o1, eB = pr_s ? o4 : o3;
+                        const int xc = wl_ + pr_s;
+                        const bool u0 = h >= 0, u1 = h + 1 >= 0 && h + 1 <= q.H - 1, lx = xc >= 0 && xc <= q.W - 1;
+                        const int ya = min(max(h, 0), q.H - 1), yb = min(max(h + 1, 0), q.H - 1), xa = min(max(xc, 0), q.W - 1);
 #pragma unroll
-                    for (int hh_ = 0; hh_ < NR; ++hh_) {
-                        const float4_t a1 = *reinterpret_cast<const float4_t *>(slab + ((long)ya * q.W + xa) * GC + hh_ * 16);
-                        const float4_t a2 = *reinterpret_cast<const float4_t *>(slab + ((long)ya * q.W + xb) * GC + hh_ * 16);
-                        const float4_t a3 = *reinterpret_cast<const float4_t *>(slab + ((long)yb * q.W + xa) * GC + hh_ * 16);
-                        const float4_t a4 = *reinterpret_cast<const float4_t *>(slab + ((long)yb * q.W + xb) * GC + hh_ * 16);
+                        for (int t = 0; t < 4; ++t) {
+                            const int ch = 8 * (pr_rank ^ t);
+                            const float4_t vT = *reinterpret_cast<const float4_t *>(slab + ((long)ya * q.W + xa) * GC + ch);
+                            const float4_t vB = *reinterpret_cast<const float4_t *>(slab + ((long)yb * q.W + xa) * GC + ch);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)   // selects (not multiplies by 0): a non-finite value at a clamped address must not leak
-                            acc[hh_][c] += w[0] * ((u0 && l0) ? a1[c] : 0.f) + w[1] * ((u0 && l1) ? a2[c] : 0.f) +
-                                           w[2] * ((u1 && l0) ? a3[c] : 0.f) + w[3] * ((u1 && l1) ? a4[c] : 0.f);
+                            for (int c = 0; c < 4; ++c)   // selects (not multiplies by 0): a non-finite value at a clamped address must not leak
+                                acc[t][c] += eT * ((u0 && lx) ? vT[c] : 0.f) + eB * ((u1 && lx) ? vB[c] : 0.f);
+                        }
+                        dma_round();
                     }
-                    dma_round();
                 }
-            }
-            DP_TICK(4)   // gather + interleaved DMA issue
-            if (cur.pok) {
-                float *o = out + ((((long)cur.b * q.Ho + cur.oy) * q.Wo + cur.ox) * q.G + cur.g) * CPG + k * 4;
+                DP_TICK(4)   // gather + interleaved DMA issue
+                // left + right column: this lane keeps reads (0,1) [pr_s = 0] or (2,3) [pr_s = 1], hands the other two to its
+                // partner lane (lane ^ 2) and stores its two 16-byte pieces
+                float o[8];
 #pragma unroll
-                for (int h = 0; h < NR; ++h) *reinterpret_cast<float4_t *>(o + h * 16) = (float4_t){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+                for (int c = 0; c < 8; ++c) {
+                    const float keep = pr_s ? acc[2 + (c >> 2)][c & 3] : acc[c >> 2][c & 3];
+                    const float give = pr_s ? acc[c >> 2][c & 3] : acc[2 + (c >> 2)][c & 3];
+                    o[c] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0x4E, 0xf, 0xf, false));
+                }
+                if (cur.pok) {
+                    float *op = out + ((((long)cur.b * q.Ho + cur.oy) * q.Wo + cur.ox) * q.G + cur.g) * CPG + pr_p * 4;
+                    const int t0 = pr_s * 2;
+                    *reinterpret_cast<float4_t *>(op + 8 * (pr_rank ^ t0)) = (float4_t){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<float4_t *>(op + 8 * (pr_rank ^ (t0 + 1))) = (float4_t){o[4], o[5], o[6], o[7]};
+                }
+            } else {
+            float acc[NR][4];
+    #pragma unroll
+                for (int h = 0; h < NR; ++h)
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[h][c] = 0.f;
+                if (cur_hot) {
+                    const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char *)smem + so;
+    #define DP_POINT(R_, LQ)                                                                                          \
+        if (LQ + 4 * R_ < K && !(DP_ABLATE & 2)) {                                                                                        \
+            const int t0 = dp_qbi<LQ>(pc.top[R_]) + lbase, t1 = dp_qbi<LQ>(pc.bot[R_]) + lbase;                       \
+            float4_t a1, a2, a3, a4, c1, c2, c3, c4;                                                                  \
+            /* the reads are ISSUED here and WAITED for after the DMA round: the round's address arithmetic and the issue stall */ \
+            /* of its global_load_lds hide behind the LDS round trip.  The destination registers are named again only by the   */ \
+            /* waiting statement, so the compiler has no reason to touch them in between.                                      */ \
+            if constexpr (NR == 2) {                                                                                  \
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:128\n\t"                              \
+                             "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:128\n\t"                              \
+                             "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:192\n\t"                    \
+                             "ds_read_b128 %6, %9 offset:64\n\tds_read_b128 %7, %9 offset:192"                         \
+                             : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4) \
+                             : "v"(t0), "v"(t1) : "memory");                                                          \
+            } else {                                                                                                  \
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\t"                               \
+                             "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"                                   \
+                             : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4) : "v"(t0), "v"(t1) : "memory");             \
+                c1 = c2 = c3 = c4 = (float4_t){0.f, 0.f, 0.f, 0.f};                                                   \
+            }                                                                                                         \
+            dma_round();                                                                                              \
+            if constexpr (NR == 2) {                                                                                  \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4) : : "memory"); \
+            } else {                                                                                                  \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : : "memory");           \
+            }                                                                                                         \
+            const float e1 = dp_qbf<LQ>(pc.w1[R_]), e2 = dp_qbf<LQ>(pc.w2[R_]), e3 = dp_qbf<LQ>(pc.w3[R_]),           \
+                        e4 = dp_qbf<LQ>(pc.w4[R_]);                                                                   \
+            _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                        \
+                float2_t t = {acc[0][c], acc[0][c + 1]};                                                              \
+                t = dp_fma2(e1, (float2_t){a1[c], a1[c + 1]}, t); t = dp_fma2(e2, (float2_t){a2[c], a2[c + 1]}, t);   \
+                t = dp_fma2(e3, (float2_t){a3[c], a3[c + 1]}, t); t = dp_fma2(e4, (float2_t){a4[c], a4[c + 1]}, t);   \
+                acc[0][c] = t.x; acc[0][c + 1] = t.y;                                                                 \
+                if constexpr (NR == 2) {                                                                              \
+                    float2_t u = {acc[NR - 1][c], acc[NR - 1][c + 1]};                                                \
+                    u = dp_fma2(e1, (float2_t){c1[c], c1[c + 1]}, u); u = dp_fma2(e2, (float2_t){c2[c], c2[c + 1]}, u); \
+                    u = dp_fma2(e3, (float2_t){c3[c], c3[c + 1]}, u); u = dp_fma2(e4, (float2_t){c4[c], c4[c + 1]}, u); \
+                    acc[NR - 1][c] = u.x; acc[NR - 1][c + 1] = u.y;                                                   \
+                }                                                                                                     \
+            }                                                                                                         \
+            /* pin the sums: otherwise the multiply-adds sink below the DMA round's branch and the loads are spilled */ \
+            _Pragma("unroll") for (int h = 0; h < NR; ++h)                                                            \
+                asm volatile("" : "+v"(acc[h][0]), "+v"(acc[h][1]), "+v"(acc[h][2]), "+v"(acc[h][3]));                \
+        } else {                                                                                                      \
+            dma_round();                                                                                              \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);
+                    // (the +128 / +192 immediates are the right-hand pixel of the corner pair: PXB = 128 for 32 channels; for 16
+                    // channels a pixel is 64 bytes and the pair's second pixel sits at +64)
+                    DP_POINT(0, 0) DP_POINT(0, 1) DP_POINT(0, 2) DP_POINT(0, 3)
+                    DP_POINT(1, 0) DP_POINT(1, 1) DP_POINT(1, 2) DP_POINT(1, 3)
+                    DP_POINT(2, 0)
+    #undef DP_POINT
+                } else {
+                    // cold tile: corners from global memory (clamped addresses, selects decide what contributes)
+                    const float *slab = in + (long)cur.b * q.H * q.W * GC + (long)cur.g * CPG + k * 4;
+                    for (int p = 0; p < K; ++p) {
+                        const int src = ((lane & ~3) | (p & 3)) << 2, r = p >> 2;
+                        const int tb_x = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.top[0] : r == 1 ? pc.top[1] : pc.top[2]);
+                        const int tb_y = __builtin_amdgcn_ds_bpermute(src, r == 0 ? pc.bot[0] : r == 1 ? pc.bot[1] : pc.bot[2]);
+                        float w[4];
+                        w[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w1[0] : r == 1 ? pc.w1[1] : pc.w1[2])));
+                        w[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w2[0] : r == 1 ? pc.w2[1] : pc.w2[2])));
+                        w[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w3[0] : r == 1 ? pc.w3[1] : pc.w3[2])));
+                        w[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r == 0 ? pc.w4[0] : r == 1 ? pc.w4[1] : pc.w4[2])));
+                        const int h = tb_x, wl_ = tb_y;
+                        const bool u0 = h >= 0, u1 = h + 1 >= 0 && h + 1 <= q.H - 1, l0 = wl_ >= 0, l1 = wl_ + 1 >= 0 && wl_ + 1 <= q.W - 1;
+                        const int ya = min(max(h, 0), q.H - 1), yb = min(max(h + 1, 0), q.H - 1);
+                        const int xa = min(max(wl_, 0), q.W - 1), xb = min(max(wl_ + 1, 0), q.W - 1);
+    #pragma unroll
+                        for (int hh_ = 0; hh_ < NR; ++hh_) {
+                            const float4_t a1 = *reinterpret_cast<const float4_t *>(slab + ((long)ya * q.W + xa) * GC + hh_ * 16);
+                            const float4_t a2 = *reinterpret_cast<const float4_t *>(slab + ((long)ya * q.W + xb) * GC + hh_ * 16);
+                            const float4_t a3 = *reinterpret_cast<const float4_t *>(slab + ((long)yb * q.W + xa) * GC + hh_ * 16);
+                            const float4_t a4 = *reinterpret_cast<const float4_t *>(slab + ((long)yb * q.W + xb) * GC + hh_ * 16);
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c)   // selects (not multiplies by 0): a non-finite value at a clamped address must not leak
+                                acc[hh_][c] += w[0] * ((u0 && l0) ? a1[c] : 0.f) + w[1] * ((u0 && l1) ? a2[c] : 0.f) +
+                                               w[2] * ((u1 && l0) ? a3[c] : 0.f) + w[3] * ((u1 && l1) ? a4[c] : 0.f);
+                        }
+                        dma_round();
+                    }
+                }
+                DP_TICK(4)   // gather + interleaved DMA issue
+                if (cur.pok) {
+                    float *o = out + ((((long)cur.b * q.Ho + cur.oy) * q.Wo + cur.ox) * q.G + cur.g) * CPG + k * 4;
+    #pragma unroll
+                    for (int h = 0; h < NR; ++h) *reinterpret_cast<float4_t *>(o + h * 16) = (float4_t){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+                }
             }
             if (PROF) pacc[8] += 1;
         }
