@@ -123,14 +123,16 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
     float2_t o2f[3];   // offsets / mask values of the tile AFTER next, in flight
     float wgf[3];
     auto prefetch = [&](const Tile &c) {
-        const long sidx = (((long)c.b * q.Ho + (c.pok ? c.oy : 0)) * q.Wo + (c.pok ? c.ox : 0)) * q.G + c.g;
+        // (32-bit element indices: N * Ho * Wo * G * K * 2 < 2^31 is a host check)
+        const unsigned sidx = (unsigned)(((c.b * q.Ho + (c.pok ? c.oy : 0)) * q.Wo + (c.pok ? c.ox : 0)) * q.G + c.g);
+        const unsigned e0 = sidx * (unsigned)K + (unsigned)k;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int p = k + 4 * r;
             o2f[r] = (float2_t){0.f, 0.f}; wgf[r] = 0.f;
             if (p < K && c.pok) {
-                o2f[r] = *reinterpret_cast<const float2_t *>(off + (sidx * K + p) * 2);
-                wgf[r] = msk[sidx * K + p];
+                o2f[r] = *reinterpret_cast<const float2_t *>(off + (size_t)((e0 + 4u * r) * 2u));
+                wgf[r] = msk[(size_t)(e0 + 4u * r)];
             }
         }
     };
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
                         const int h = (int)floorf(loc_h), w = (int)floorf(loc_w);
                         const float lh = loc_h - (float)h, lw = loc_w - (float)w, hh = 1.f - lh, hw = 1.f - lw;
                         okp[r] = true; hl[r] = h; wl[r] = w;
-                        pn.w1[r] = hh * hw * wgt; pn.w2[r] = hh * lw * wgt; pn.w3[r] = lh * hw * wgt; pn.w4[r] = lh * lw * wgt;
+                        const float ht = hh * wgt, lt = lh * wgt;   // (mask value folded in: 6 multiplies instead of 8)
+                        pn.w1[r] = ht * hw; pn.w2[r] = ht * lw; pn.w3[r] = lt * hw; pn.w4[r] = lt * lw;
                         ymin = min(ymin, h); ynmin = min(ynmin, -h); xmin = min(xmin, w); xnmin = min(xnmin, -w);
                     }
                 }
@@ -506,7 +509,8 @@ int dp_go(const float *in, const float *off, const float *msk, const Dcnv3Geo &q
 bool dcnv3_pipe_ok(const Dcnv3Geo &q)
 {
     return (long)q.N * q.G * ((q.Ho + DP_TH - 1) / DP_TH) * ((q.Wo + DP_TW - 1) / DP_TW) < (1L << 22) &&   // (dp_div operand range)
-           (long)q.H * q.W * q.G * q.C * 4 < (1L << 31);   // 32-bit byte offsets inside one image
+           (long)q.H * q.W * q.G * q.C * 4 < (1L << 31) &&   // 32-bit byte offsets inside one image
+           (long)q.N * q.Ho * q.Wo * q.G * q.kh * q.kw * 2 < (1L << 31);   // 32-bit offset / mask element indices
 }
 
 int dcnv3_pipe_launch(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out, int prof,
