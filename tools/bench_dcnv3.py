@@ -27,7 +27,10 @@ def timeit(fn, iters=20, warmup=3):
 def main():
     dev = "cuda:0"
     torch.manual_seed(0)
-    for N, H, W, G, C in ((8, 336, 336, 10, 32), (8, 168, 168, 20, 32), (8, 84, 84, 40, 32), (8, 42, 42, 80, 32)):
+    shapes = ((8, 336, 336, 10, 32), (8, 168, 168, 20, 32), (8, 84, 84, 40, 32), (8, 42, 42, 80, 32))
+    if os.environ.get("DCN_C16"):   # group channels 16 (InternImage-T/S/B): 64 / 128 / 256 / 512 channels
+        shapes = ((8, 336, 336, 4, 16), (8, 168, 168, 8, 16), (8, 84, 84, 16, 16), (8, 42, 42, 32, 16))
+    for N, H, W, G, C in shapes:
         k = 3
         x = torch.randn(N, H, W, G * C, device=dev)
         off = torch.randn(N, H, W, G * k * k * 2, device=dev) * float(os.environ.get("DCN_OFFSET_SIGMA", "1.0"))
