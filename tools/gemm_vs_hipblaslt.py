@@ -21,7 +21,6 @@ for name, N, K, epi in (("qkv", 3072, 1024, 0), ("proj", 1024, 1024, 0), ("fc1",
     _lib.set_option('gemm_direct_store', 0)
     vialds = timeit(lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), Mm, N, K, K, K, N, epi, None, None, 0, 0, st)))
     _lib.set_option('gemm_direct_store', 2)
-    w4 = timeit(lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), Mm, N, K, K, K, N, epi | 0x400, None, None, 0, 0, st)))
     lib = timeit(lambda: torch.nn.functional.linear(x, w, b))
     fl = 2.0 * Mm * N * K
-    print(json.dumps(dict(shape=name, M=Mm, N=N, K=K, ours_us=ours * 1e6, ours_TF=fl / ours / 1e12, direct_store_us=direct * 1e6, via_lds_us=vialds * 1e6, w4_us=w4 * 1e6, w4_TF=fl / w4 / 1e12, hipblaslt_us=lib * 1e6, hipblaslt_TF=fl / lib / 1e12)))
+    print(json.dumps(dict(shape=name, M=Mm, N=N, K=K, ours_us=ours * 1e6, ours_TF=fl / ours / 1e12, direct_store_us=direct * 1e6, via_lds_us=vialds * 1e6, hipblaslt_us=lib * 1e6, hipblaslt_TF=fl / lib / 1e12)))
