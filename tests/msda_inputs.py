@@ -32,7 +32,8 @@ def make_inputs(B, M, D, shapes, P, Lq=None, mode="encoder_like", seed=0, dtype=
     L = len(shapes)
     S = int(sum(h * w for h, w in shapes))
     value = rng.standard_normal((B, S, M, D), dtype=np.float32)
-    if mode == "encoder_like":
+    if mode in ("encoder_like", "encoder_wide"):   # encoder_wide: the same pattern with 3x the offsets and jitter (trained heads)
+        spread = 3.0 if mode == "encoder_wide" else 1.0
         ref = reference_grid(shapes)  # [S,2]
         if Lq is None or Lq == S:
             Lq = S
@@ -48,7 +49,7 @@ def make_inputs(B, M, D, shapes, P, Lq=None, mode="encoder_like", seed=0, dtype=
         loc = np.empty((B, Lq, M, L, P, 2), dtype=np.float32)
         for b in range(B):
             jit = rng.standard_normal((Lq, M, L, P, 2), dtype=np.float32) * 0.5
-            loc[b] = q_ref[:, None, None, None, :] + (off[None] + jit) / wh[None, None, :, None, :]
+            loc[b] = q_ref[:, None, None, None, :] + spread * (off[None] + jit) / wh[None, None, :, None, :]
     elif mode == "stress":
         Lq = Lq or 64
         loc = rng.random((B, Lq, M, L, P, 2), dtype=np.float32) * 1.1 - 0.05
