@@ -1,5 +1,5 @@
 """Shader clock / package power sampled with rocm-smi while one kernel runs in a tight loop (is the part power- or
-current-limited under this kernel?).  usage: clock_under_load.py attn|gemm|msda|idle [seconds]"""
+current-limited under this kernel?).  usage: clock_under_load.py attn|attn_zeros|attn_small|gemm|gemm_zeros|msda|dcnv3|idle [seconds]"""
 import os, subprocess, sys, threading, time, re
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,13 +8,15 @@ L = _lib.lib(); st = _lib.current_stream()
 what = sys.argv[1] if len(sys.argv) > 1 else "attn"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
 
-if what == "attn":
+if what.startswith("attn"):
     n, S, H, D = 40, 577, 16, 64
-    qkv = torch.randn(n, S, 3, H, D, device="cuda").bfloat16(); out = torch.empty(n, S, H, D, device="cuda", dtype=torch.bfloat16)
+    qkv = (torch.zeros(n, S, 3, H, D, device="cuda") if what == "attn_zeros" else
+           torch.randn(n, S, 3, H, D, device="cuda") * (1e-3 if what == "attn_small" else 1.0)).bfloat16(); out = torch.empty(n, S, H, D, device="cuda", dtype=torch.bfloat16)
     fn = lambda: _lib.check(L.vllm_attn_fwd_qkvpacked_bf16(_lib.ptr(qkv), _lib.ptr(out), n, S, H, D, D ** -0.5, st))
-elif what == "gemm":
+elif what.startswith("gemm"):
     M, N, K = 23080, 4096, 1024
-    x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+    z = 0.0 if what == "gemm_zeros" else 1.0
+    x = (torch.randn(M, K, device="cuda") * z).bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02 * z).bfloat16()
     b = torch.zeros(N, device="cuda").bfloat16(); y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     fn = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, N, K, K, K, N, 2, None, None, 0, 0, st))
 elif what == "msda":
@@ -23,6 +25,12 @@ elif what == "msda":
     t = bench.build_msda_inputs("cuda", 8, 1)["enc"]
     from visionllm_amd import ms_deform_attn as A
     fn = lambda: A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)
+elif what == "dcnv3":
+    from visionllm_amd import dcnv3 as DC
+    N_, H_, W_, G_, C_, k_ = 8, 168, 168, 20, 32, 3
+    xi = torch.randn(N_, H_, W_, G_ * C_, device="cuda"); of = torch.randn(N_, H_, W_, G_ * k_ * k_ * 2, device="cuda")
+    mk = torch.softmax(torch.randn(N_, H_, W_, G_, k_ * k_, device="cuda"), -1).reshape(N_, H_, W_, -1)
+    fn = lambda: DC.dcnv3_forward(xi, of, mk, k_, k_, 1, 1, 1, 1, 1, 1, G_, C_, 1.0)
 else:
     fn = lambda: time.sleep(0.001)
 
