@@ -13,12 +13,22 @@ if what.startswith("attn"):
     qkv = (torch.zeros(n, S, 3, H, D, device="cuda") if what == "attn_zeros" else
            torch.randn(n, S, 3, H, D, device="cuda") * (1e-3 if what == "attn_small" else 1.0)).bfloat16(); out = torch.empty(n, S, H, D, device="cuda", dtype=torch.bfloat16)
     fn = lambda: _lib.check(L.vllm_attn_fwd_qkvpacked_bf16(_lib.ptr(qkv), _lib.ptr(out), n, S, H, D, D ** -0.5, st))
-elif what.startswith("gemm"):
+elif what in ("gemm", "gemm_zeros"):
     M, N, K = 23080, 4096, 1024
     z = 0.0 if what == "gemm_zeros" else 1.0
     x = (torch.randn(M, K, device="cuda") * z).bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02 * z).bfloat16()
     b = torch.zeros(N, device="cuda").bfloat16(); y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     fn = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, N, K, K, K, N, 2, None, None, 0, 0, st))
+elif what == "hipblaslt":   # the same fc1 shape through torch (hipBLASLt), bias only
+    M, N, K = 23080, 4096, 1024
+    x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+    b = torch.zeros(N, device="cuda").bfloat16()
+    fn = lambda: torch.nn.functional.linear(x, w, b)
+elif what == "gemm_bias":   # ours, bias only (the like-for-like of hipblaslt)
+    M, N, K = 23080, 4096, 1024
+    x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+    b = torch.zeros(N, device="cuda").bfloat16(); y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    fn = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, N, K, K, K, N, 0, None, None, 0, 0, st))
 elif what == "msda":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import bench

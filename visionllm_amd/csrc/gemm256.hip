@@ -122,6 +122,47 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // Residual epilogue without LayerScale (the CLIP encoder's proj / fc2): the residual tile becomes the INITIAL VALUE of the
+        // accumulators -- res + (X W^T + bias) = (res + X W^T) + bias in fp32, one rounding at the end as before.  A lane owns 4
+        // features of one token, so reading the tile in the accumulator layout is 32 eight-byte loads per lane that touch 16 rows x
+        // 32 bytes each: 18-24 K cycles per tile wherever they are issued (phase clock: epilogue 7.6 K -> 24-30 K; as plain loads
+        // in front of the prologue the same 18-24 K).  Here the tile comes in row-wise instead -- LDS-DMA, 16 bytes per lane, 512
+        // contiguous bytes per row, into the (still empty) ring, 16-byte chunk c of row r at chunk c ^ (r & 31) -- and the
+        // lanes pick their elements up with conflict-free ds_read_b64.
+        if (EPI == EPI_RESIDUAL && a.res_init) {
+            constexpr int RROWS = 64 * MT;                       // rows of the block tile
+#pragma unroll
+            for (int s = 0; s < RROWS / 16; ++s) {               // 8 waves x 2 rows x 512 B per round
+                const int r = s * 16 + wave * 2 + (lane >> 5);
+                const int pp = lane & 31;                        // chunk position in the LDS row
+                const int c = pp ^ (r & 31);                     // source chunk that must land there
+                int gm = m0 + r;
+                gm = gm < a.M ? gm : a.M - 1;
+                int gn = n0 + c * 8;
+                gn = gn < a.N ? gn : a.N - 8;                    // (N % 8 == 0 on this route: launcher)
+                const uint16_t *g = a.res + (size_t)gm * a.ldr + gn;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(smem + (s * 16 + wave * 2) * 512), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;   // column of the tile: chunk nl / 8, half (nl / 4) & 1
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) {
+                        const int ml = qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr;
+                        const uint2_t rr = *reinterpret_cast<const uint2_t *>(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + ((nl >> 2) & 1) * 8);
+                        acc[q][i][j] = (f32x4_t){bf16lo_to_f32(rr.x), bf16hi_to_f32(rr.x), bf16lo_to_f32(rr.y), bf16hi_to_f32(rr.y)};
+                    }
+                }
+            }
+            G2_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();                        // the ring is free again: the prologue's DMA may overwrite it
+        }
     }
 
     // per-lane LDS byte offsets inside a half-tile for the two fragment kinds (ks = 0 / 1 differ by XOR 4 chunks)
@@ -431,6 +472,12 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     }
 }
 
+static bool res_init_disabled()
+{
+    static const int v = [] { const char *e = getenv("VLLM_GEMM_RES_INIT"); return e && e[0] == '0' ? 1 : 0; }();   // A/B switch
+    return v != 0;
+}
+
 int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 {
     static int cus = 0;
@@ -441,6 +488,8 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                   ? prop.multiProcessorCount : 256;
     }
     a.nt = ceil_div(a.N, G2_BN);
+    a.res_init = (epi == EPI_RESIDUAL && a.scale == nullptr && a.variant256 != 5 && !res_init_disabled() && a.N % 8 == 0 && a.N >= 8 &&
+                  a.ldr % 8 == 0 && aligned16(a.res)) ? 1 : 0;
     { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
     { static unsigned long long *const tr = [] { const char *e = getenv("VLLM_GEMM_TRACE"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : (unsigned long long *)nullptr; }(); a.trace = tr; }
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs

@@ -36,6 +36,7 @@ struct GemmArgs {
     const float *ref = nullptr;       // [M, mL, ref_dim] reference points
     const int64_t *shapes = nullptr;  // [mL, 2] (H, W)
     int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
+    int res_init = 0;       // EPI_RESIDUAL without LayerScale, 8-phase kernel: the residual is the accumulators' initial value (launcher)
     int prof = 0;           // VLLM_GEMM_PROF=1: the 8-phase kernel adds prologue / main loop / epilogue ticks to device counters
     unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
                                            // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
