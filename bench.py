@@ -155,24 +155,28 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
                        us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=NL)
     del qkv, ao
     # the four encoder GEMMs + the projector GEMMs
-    gemms = [("gemm_qkv", M, 3 * C, C, 0, NL), ("gemm_proj", M, C, C, 0, NL), ("gemm", M, I, C, act, NL), ("gemm_fc2", M, C, I, 0, NL)]
+    # epilogues as the encoder uses them: 3 = bias (+ LayerScale for InternViT) + residual
+    gemms = [("gemm_qkv", M, 3 * C, C, 0, NL), ("gemm_proj", M, C, C, 3, NL), ("gemm", M, I, C, act, NL), ("gemm_fc2", M, C, I, 3, NL)]
     gemms += [(f"gemm_bridge{i}", m, n, k, 0, 1) for i, (m, n, k) in enumerate(bridge_dims)]
-    names = {"gemm": "MLP fc1", "gemm_qkv": "QKV", "gemm_proj": "attention out-proj (+LayerScale/residual in the step)",
-             "gemm_fc2": "MLP fc2 (+LayerScale/residual in the step)"}
+    has_ls = "qk_normalization" in cfg   # InternViT: LayerScale in the residual epilogue; CLIP: plain residual
+    names = {"gemm": "MLP fc1 + activation", "gemm_qkv": "QKV", "gemm_proj": "attention out-proj + " + ("LayerScale + " if has_ls else "") + "residual",
+             "gemm_fc2": "MLP fc2 + " + ("LayerScale + " if has_ls else "") + "residual"}
     for nm, m, n, k, epi, n_launch in gemms:
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
         b = torch.zeros(n, device=dev).to(torch.bfloat16)
         y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        res = torch.randn(m, n, device=dev).to(torch.bfloat16) if epi == 3 else None
+        ls = torch.full((n,), 0.1, device=dev).to(torch.bfloat16) if (epi == 3 and has_ls) else None
         f = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, n, k, k, k, n, epi,  # noqa: E731
-                                                 None, None, 0, 0, st))
+                                                 _lib.ptr(ls), _lib.ptr(res), n if epi == 3 else 0, 0, st))
         f(); torch.cuda.synchronize()
         sec = event_time(f, iters)
         fl = 2.0 * m * n * k
         out[nm] = dict(kernel=f"gemm256_bf16_kernel ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", bound="mfma",
                        achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF,
                        traffic=None, us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=n_launch)
-        del x, w, b, y
+        del x, w, b, y, res, ls
     # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

@@ -77,12 +77,14 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
 // quadrant piece is then two 32(m) x 32(n) blocks, 8 MFMAs per phase; fragments are 16 bytes of one row per lane
 // (row = lane & 31, k half = lane >> 5), the k16 step ks selects chunk pair 2ks, 2ks+1 -> byte offset ^ (ks << 5).
 template <int EPI, int MT, bool MF32 = false>
-__global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmArgs a)
+__global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmArgs a0_)
 {
     static_assert(!MF32 || MT == 4, "32x32x16 path: 256-row tiles only");
     typedef float f32x16_t __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    GemmArgs al = a0_;            // (block-local copy: res_init may be switched off for this block, see below)
+    const GemmArgs &a = al;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, kq = lane >> 4;
 
@@ -106,6 +108,17 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     const unsigned long long rt_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int nk = a.K / G2_BK;
 
+    // Residual as accumulator init (below) with a LayerScale needs 1 / ls: every block checks ITS 256 columns (finite, |ls| >=
+    // 1e-4: the division must not blow the fp32 accumulation up) and keeps the plain epilogue otherwise -- block-uniform.
+    if (EPI == EPI_RESIDUAL && al.res_init && al.scale) {
+        const int t = threadIdx.x;
+        bool ok = true;
+        if (t < G2_BN && n0 + t < al.N) {
+            const float v = bf16_to_f32(al.scale[n0 + t]);
+            ok = fabsf(v) >= 1e-4f && fabsf(v) < 1e30f;
+        }
+        if (!__syncthreads_and(ok ? 1 : 0)) al.res_init = 0;
+    }
     f32x4_t acc[MF32 ? 1 : 4][2][MT];   // [quadrant q = 2*i + j][n tile][m tile]
     f32x16_t acc32[MF32 ? 4 : 1][2];     // MF32: [quadrant][m block of 32]
     if constexpr (MF32) {
@@ -152,11 +165,17 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;   // column of the tile: chunk nl / 8, half (nl / 4) & 1
+                    float il[4] = {1.f, 1.f, 1.f, 1.f};                     // 1 / LayerScale of this lane's 4 features
+                    if (a.scale && n0 + nl < a.N) {
+                        const uint2_t sv = *reinterpret_cast<const uint2_t *>(a.scale + n0 + nl);
+                        il[0] = __builtin_amdgcn_rcpf(bf16lo_to_f32(sv.x)); il[1] = __builtin_amdgcn_rcpf(bf16hi_to_f32(sv.x));   // (1 ulp: the round trip
+                        il[2] = __builtin_amdgcn_rcpf(bf16lo_to_f32(sv.y)); il[3] = __builtin_amdgcn_rcpf(bf16hi_to_f32(sv.y));   //  res / ls * ls costs 2^-23 |res|)
+                    }
 #pragma unroll
                     for (int j = 0; j < MT; ++j) {
                         const int ml = qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr;
                         const uint2_t rr = *reinterpret_cast<const uint2_t *>(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + ((nl >> 2) & 1) * 8);
-                        acc[q][i][j] = (f32x4_t){bf16lo_to_f32(rr.x), bf16hi_to_f32(rr.x), bf16lo_to_f32(rr.y), bf16hi_to_f32(rr.y)};
+                        acc[q][i][j] = (f32x4_t){bf16lo_to_f32(rr.x) * il[0], bf16hi_to_f32(rr.x) * il[1], bf16lo_to_f32(rr.y) * il[2], bf16hi_to_f32(rr.y) * il[3]};
                     }
                 }
             }
@@ -488,7 +507,7 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                   ? prop.multiProcessorCount : 256;
     }
     a.nt = ceil_div(a.N, G2_BN);
-    a.res_init = (epi == EPI_RESIDUAL && a.scale == nullptr && a.variant256 != 5 && !res_init_disabled() && a.N % 8 == 0 && a.N >= 8 &&
+    a.res_init = (epi == EPI_RESIDUAL && a.variant256 != 5 && !res_init_disabled() && a.N % 8 == 0 && a.N >= 8 &&
                   a.ldr % 8 == 0 && aligned16(a.res)) ? 1 : 0;
     { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
     { static unsigned long long *const tr = [] { const char *e = getenv("VLLM_GEMM_TRACE"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : (unsigned long long *)nullptr; }(); a.trace = tr; }

@@ -62,7 +62,10 @@ __device__ __forceinline__ void epi_value(const GemmArgs &a, int m, int n, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
     } else if (EPI == EPI_RESIDUAL && a.res_init) {
-        // the residual went in as the accumulators' initial value (gemm256: no LayerScale) -- acc + bias is the result
+        // the residual went in as the accumulators' initial value (gemm256), divided by the LayerScale where there is one:
+        // (res / ls + X W^T + bias) * ls = res + (X W^T + bias) * ls   (scl = 1 without LayerScale)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= c.scl[r];
     } else if (EPI == EPI_RESIDUAL) {
         const uint2_t rr = *reinterpret_cast<const uint2_t *>(a.res + (size_t)m * a.ldr + n);
         v[0] = bf16lo_to_f32(rr.x) + v[0] * c.scl[0]; v[1] = bf16hi_to_f32(rr.x) + v[1] * c.scl[1];
