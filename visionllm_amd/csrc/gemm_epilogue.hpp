@@ -59,8 +59,13 @@ __device__ __forceinline__ void epi_value(const GemmArgs &a, int m, int n, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     } else if (EPI == EPI_QUICK_GELU) {
+        // x * sigmoid(1.702 x), x = acc + bias: the exponent -1.702 log2(e) (acc + bias) is ONE fma of the accumulator (the bias
+        // times the constant is per column) instead of add + multiply -- 5.5 instead of 6.5 VALU per element of a tile whose
+        // epilogue nothing overlaps
+        constexpr float kq = -1.702f * 1.4426950408889634f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+        for (int r = 0; r < 4; ++r)
+            v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[r], kq, c.bia[r] * kq)));
     } else if (EPI == EPI_RESIDUAL && a.res_init) {
         // the residual went in as the accumulators' initial value (gemm256), divided by the LayerScale where there is one:
         // (res / ls + X W^T + bias) * ls = res + (X W^T + bias) * ls   (scl = 1 without LayerScale)
