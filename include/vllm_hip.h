@@ -92,6 +92,20 @@ int vllm_msda_forward_f64(const double *value, const int64_t *shapes, const int6
                           const double *loc, const double *attw,
                           int B, int S, int M, int D, int L, int Lq, int P,
                           double *out, vllm_stream_t stream);
+/* vllm_msda_forward_f32 for a caller that knows the level geometry on the HOST.  `shapes` is device memory (as in the
+ * reference), so by itself the library cannot know whether the level maps form an exact 2x pyramid whose cells are the Lq
+ * queries (the det heads' 168^2 / 84^2 / 42^2 / 21^2 encoder case, served by the pyramid-item kernel) without a host
+ * synchronisation: VLLM_GEO_UNKNOWN enqueues the pyramid kernel AND the any-geometry kernel and the device picks (one
+ * empty launch).  The reference's modules synchronise once per forward pass anyway (`(H * W).sum() == Len_in`,
+ * ms_deform_attn.py:100); the Python mirror learns the geometry in that same read-back and passes it here: exactly one
+ * launch.  A PYRAMID hint that the device-side test contradicts traps (the hint is never trusted for addressing). */
+#define VLLM_GEO_UNKNOWN 0
+#define VLLM_GEO_PYRAMID 1
+#define VLLM_GEO_GENERAL 2
+int vllm_msda_forward_f32_geo(const float *value, const int64_t *shapes, const int64_t *lsi,
+                              const float *loc, const float *attw,
+                              int B, int S, int M, int D, int L, int Lq, int P, int geometry,
+                              float *out, vllm_stream_t stream);
 /* bf16 value/out, fp32 loc/attw, fp32 accumulation (extension: the reference upcasts bf16 to fp32 first,
  * modeling_ov_grounding_dino_mask_dn.py:764-766; this variant halves the gathered bytes). */
 int vllm_msda_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
@@ -133,6 +147,8 @@ typedef struct VllmMsdaLayerDesc {
     int32_t d_model, n_heads, n_levels, n_points;
     int32_t ref_dim;             /* last dim of reference_points: 2 or 4 */
     int32_t use_4d_normalizer;   /* ref_dim 4 only: UniPose's use_4D_normalizer */
+    int32_t geometry;            /* VLLM_GEO_*: what the host knows about spatial_shapes (0 = nothing) */
+    int32_t reserved0;           /* 0 */
     const uint16_t *value_proj_w, *value_proj_b;                  /* [C, C], [C]           (device, bf16) */
     const uint16_t *sampling_offsets_w, *sampling_offsets_b;      /* [M*L*P*2, C], [M*L*P*2] */
     const uint16_t *attention_weights_w, *attention_weights_b;    /* [M*L*P, C], [M*L*P] */

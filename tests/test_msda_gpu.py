@@ -765,3 +765,55 @@ def test_fused_layer_module_flavours_and_fallbacks():
         A.msda_layer_forward(q, ref[..., :1].expand(-1, -1, -1, 3), src, ss, lsi, None, mod.value_proj, mod.sampling_offsets,
                              mod.attention_weights, mod.output_proj, 4, 3, 4)
 
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: host-known level geometry (one kernel launch instead of two) and inference-mode tensors
+@pytest.mark.parametrize("shapes", [[(72, 64), (36, 32), (18, 16), (9, 8)], [(61, 83), (31, 42), (9, 5)]])
+def test_geometry_hint_changes_launches_not_results(shapes):
+    """vllm_msda_forward_f32_geo: UNKNOWN (both kernels enqueued, the device picks), the hint a module's shape check leaves
+    behind (exactly one kernel) and the opposite extreme (GENERAL forced for a pyramid) give the same tensor."""
+    from visionllm_amd import _lib
+    g = make_inputs(2, 8, 32, shapes, 4, mode="encoder_like", seed=11)
+    v, ss, lsi, loc, w = _t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]), _t(g["attw"])
+    B, S, M, D = v.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    assert A.known_geometry(ss, Lq) == A.GEO_UNKNOWN          # nobody has looked at this tensor object yet
+    unknown = A.ms_deform_attn_forward(v, ss, lsi, loc, w, 64)
+    geo = A.remember_geometry(ss)
+    is_pyr = all((h << l) == shapes[0][0] and (ww << l) == shapes[0][1] for l, (h, ww) in enumerate(shapes))
+    assert geo == (A.GEO_PYRAMID if is_pyr else A.GEO_GENERAL) and A.known_geometry(ss, Lq) == geo
+    assert A.known_geometry(ss, Lq - 1) == (A.GEO_GENERAL if is_pyr else geo)   # a pyramid only for the encoder's queries
+    hinted = A.ms_deform_attn_forward(v, ss, lsi, loc, w, 64)
+    assert torch.equal(hinted, unknown)
+    ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
+    np.testing.assert_allclose(hinted.cpu().numpy(), ref, rtol=4e-6, atol=4e-6)
+    out = torch.empty_like(unknown)
+    _lib.check(_lib.lib().vllm_msda_forward_f32_geo(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(lsi), _lib.ptr(loc), _lib.ptr(w), B, S, M,
+                                                    D, L, Lq, P, A.GEO_GENERAL, _lib.ptr(out), _lib.current_stream(v.device)))
+    torch.testing.assert_close(out, unknown, rtol=2e-6, atol=2e-6)    # generation 4 instead of 7: same sums, other order
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().vllm_msda_forward_f32_geo(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(lsi), _lib.ptr(loc), _lib.ptr(w), B, S,
+                                                        M, D, L, Lq, P, 7, _lib.ptr(out), _lib.current_stream(v.device)))
+    ss.mul_(1)                                                  # an in-place change bumps the version: knowledge is dropped
+    assert A.known_geometry(ss, Lq) == A.GEO_UNKNOWN
+
+
+def test_modules_run_under_inference_mode():
+    """Inference tensors have no version counter (`t._version` raises): the shape-facts cache must not depend on it
+    (level_pixels crashed every module under torch.inference_mode(), the normal way to serve)."""
+    shapes = [(12, 16), (6, 8), (3, 4)]
+    mod, q, ref, src, ss, lsi, mask = _layer_case(2, shapes, 40, 2, 0, seed=5, C=128, M=4)
+    with torch.no_grad():
+        expect = mod(q, ref, src, ss, lsi, mask)
+    with torch.inference_mode():
+        ss_i = torch.tensor(shapes, dtype=torch.int64, device=DEV)          # an inference tensor
+        with pytest.raises(RuntimeError):
+            ss_i._version
+        assert A.level_pixels(ss_i) == sum(h * w for h, w in shapes)
+        assert A.known_geometry(ss_i, 40) == A.GEO_UNKNOWN                   # never cached: a change could not be seen
+        got = mod(q, ref, src, ss_i, lsi, mask)
+        assert torch.equal(got, expect)
+        m32 = A.MSDeformAttn(d_model=128, n_levels=3, n_heads=4, n_points=4).to(DEV).eval()   # fp32: the composed path
+        o32 = m32(q.float(), ref, src.float(), ss_i, lsi, mask)
+        assert torch.isfinite(o32).all()

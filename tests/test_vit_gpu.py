@@ -223,9 +223,17 @@ def _attn_ref(qkv, H, D, scale):
     return V.attention_core(q, k, v, scale).reshape(B, S, H, D)
 
 
+@pytest.fixture(params=[32, 64], ids=["sched_auto", "sched2"])
+def attn_sched(request):
+    """Run a test under the automatic schedule and under schedule 2 (attn2.hip) explicitly."""
+    old = _lib.set_option("attn_variant", request.param)
+    yield request.param
+    _lib.set_option("attn_variant", old)
+
+
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("S", [1, 5, 32, 33, 63, 64, 65, 96, 97, 128, 129, 577, 1025])
-def test_attention_vs_oracle(D, S):
+def test_attention_vs_oracle(D, S, attn_sched):
     torch.manual_seed(S * 3 + D)
     B, H = 2, 3
     qkv = bf(torch.randn(B, S, 3, H, D, device=DEV))
@@ -244,7 +252,7 @@ def test_attention_vs_oracle(D, S):
 
 
 @pytest.mark.parametrize("D", [64, 128])
-def test_attention_online_softmax_rescale_branch(D):
+def test_attention_online_softmax_rescale_branch(D, attn_sched):
     """cdna guide rule 26: force the running max to jump at a late tile (spiked key) and at the first tile."""
     torch.manual_seed(7)
     B, H, S = 1, 2, 300
@@ -261,7 +269,7 @@ def test_attention_online_softmax_rescale_branch(D):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
-@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3, 18])   # 18: no padding trim
+@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3, 18, 64, 192, 320, 448, 576, 960, 1088, 1216])   # 18: no padding trim; 64 | v << 7: schedule 2 (v bit 3: one item per block)
 @pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
 def test_attention_schedule_variants(variant, D, S):
     """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""

@@ -29,7 +29,10 @@ def run(n, S, H, D, variants=(2,), rounds=7, reps=20):
 
 
 if __name__ == "__main__":
-    # 16 + v: the same schedule without the padding trim (short last key tile, idle padding waves)
-    run(40, 577, 16, 64, variants=(2, 18, 3, 32))   # 16 + v: the same schedule without the padding trim   # 64 + v: folded schedule (max subtraction on the MFMA, lagged max)
-    run(8, 1025, 25, 128, variants=(2, 3, 32))
-    run(40, 1025, 25, 128, variants=(2, 32))
+    # 2: round-1/2 schedule (attn.hip); 64 | v << 7: schedule 2 (attn2.hip), v bit0 setprio, bit1 split exp, bit2 add row sums
+    NEW = (64, 192, 320, 448, 576)
+    if len(sys.argv) > 1:
+        NEW = tuple(int(x) for x in sys.argv[1].split(","))
+    run(40, 577, 16, 64, variants=(2,) + NEW)
+    run(8, 1025, 25, 128, variants=(2,) + NEW)
+    run(40, 1025, 25, 128, variants=(2,) + NEW[:2])

@@ -129,7 +129,7 @@ class VllmBridgeDesc(ctypes.Structure):
 
 class VllmMsdaLayerDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("d_model", "n_heads", "n_levels", "n_points", "ref_dim",
-                                              "use_4d_normalizer")] + \
+                                              "use_4d_normalizer", "geometry", "reserved0")] + \
                [(n, _P) for n in ("value_proj_w", "value_proj_b", "sampling_offsets_w", "sampling_offsets_b",
                                   "attention_weights_w", "attention_weights_b", "output_proj_w", "output_proj_b")]
 

@@ -20,32 +20,9 @@
 #include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "attn_common.hpp"
 
 namespace vllm {
-
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-constexpr int ATT_THREADS = 256;
-constexpr int QBLK = 128;   // query rows per block
-constexpr int KVBLK = 64;   // keys per tile
-
-template <int D> __device__ __forceinline__ int swz_k(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
-template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
-
-// Combine the two key halves of a query (lanes l and l^32) with ONE v_permlane32_swap instead of a ds_bpermute round
-// trip: swapping x with itself leaves {x_lo, x_lo} in one register and {x_hi, x_hi} in the other.
-__device__ __forceinline__ float halves_max(float x)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float halves_sum(float x)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // K/V staging.  The per-lane part of every source address (row-in-tile * token stride + swizzled 16-byte chunk) does not
 // change from tile to tile: it is computed ONCE (kv_lane_offsets) and each tile's LDS-DMA is then
@@ -380,6 +357,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     }
 }
 
+
 int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
 {
     VLLM_REQUIRE(a.B >= 0 && a.S > 0 && a.H > 0, "attn: bad dims B=%d S=%d H=%d", a.B, a.S, a.H);
@@ -395,9 +373,11 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    // automatic: the plain schedule with deferred rescale wins for both head sizes (d = 64: 128 VGPRs, 4 waves per SIMD)
+    // attn_variant: 32 = automatic; bit 6 (64) selects schedule 2 (attn_fwd2_kernel) with its VAR in bits 7-9; otherwise
+    // bits 0-3 are attn_fwd_kernel's VAR and bit 4 switches the padding trim off
     int var = attn_variant();
     if (var & 32) var = 2;
+    if (var & 64) return attn_fwd2_launch(a, D, (var >> 7) & 15, st);
     a.no_trim = (var >> 4) & 1;
     var &= 15;
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)

@@ -35,7 +35,7 @@ int msda_tiled6_launch_bf16(const uint16_t *value, const int64_t *shapes, const 
                             const float *attw, int B, int S, int M, int L, int Lq, uint16_t *out, hipStream_t st);
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st,
-                      uint16_t *out16 = nullptr, int *wrote16 = nullptr);
+                      uint16_t *out16 = nullptr, int *wrote16 = nullptr, int geometry = 0);
 
 // ---------------------------------------------------------------------------------------------------------
 // Vectorised forward.
@@ -515,12 +515,12 @@ namespace vllm {
 // device-side predicate, geometry_is_pyramid).
 int msda_forward_f32_out16(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                            int B, int S, int M, int D, int L, int Lq, int P, float *out, uint16_t *out16, int *where,
-                           hipStream_t st)
+                           hipStream_t st, int geometry)
 {
     *where = 0;
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
     if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc) && (reinterpret_cast<uintptr_t>(out16) & 7u) == 0)
-        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, out16, where);
+        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, out16, where, geometry);
     return vllm_msda_forward_f32(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, (vllm_stream_t)st);
 }
 }  // namespace vllm
@@ -529,12 +529,21 @@ extern "C" int vllm_msda_forward_f32(const float *value, const int64_t *shapes, 
                                      const float *loc, const float *attw, int B, int S, int M, int D, int L,
                                      int Lq, int P, float *out, vllm_stream_t stream)
 {
+    return vllm_msda_forward_f32_geo(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, VLLM_GEO_UNKNOWN, out, stream);
+}
+
+extern "C" int vllm_msda_forward_f32_geo(const float *value, const int64_t *shapes, const int64_t *lsi,
+                                         const float *loc, const float *attw, int B, int S, int M, int D, int L,
+                                         int Lq, int P, int geometry, float *out, vllm_stream_t stream)
+{
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+    VLLM_REQUIRE(geometry == VLLM_GEO_UNKNOWN || geometry == VLLM_GEO_PYRAMID || geometry == VLLM_GEO_GENERAL,
+                 "msda_forward_f32: geometry must be VLLM_GEO_UNKNOWN / _PYRAMID / _GENERAL (got %d)", geometry);
     if ((long)B * Lq == 0) return VLLM_OK;
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc))   // encoder self-attention shape: LDS-tiled kernel
-        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
+        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, nullptr, nullptr, geometry);
     if (vec_ok(D, 4, L, P, value, out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0)
         return dispatch_vec<false>(D / 4, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
     return launch_generic_fwd<float>(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, st);

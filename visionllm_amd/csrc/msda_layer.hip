@@ -21,7 +21,7 @@ namespace vllm {
 
 int msda_forward_f32_out16(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                            int B, int S, int M, int D, int L, int Lq, int P, float *out, uint16_t *out16, int *where,
-                           hipStream_t st);   // msda.hip
+                           hipStream_t st, int geometry);   // msda.hip
 
 namespace {
 
@@ -265,9 +265,11 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     // the operator (:131-139), fp32 arithmetic; bf16 result straight from the LDS-tiled kernel where that one runs
     int where = 0;
     if (layer_unfused()) TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
-    else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st));
-    // output_proj (:144)
-    TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
+    else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st, d->geometry));
+    // output_proj (:144).  The conversion pass runs unless the host KNOWS the operator wrote bf16 (pyramid hint); with an
+    // unknown geometry it is enqueued and tests the device-side predicate itself.
+    if (!(where && d->geometry == VLLM_GEO_PYRAMID))
+        TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
     TRY(gemm(st, EPI_BIAS, opb, C, d->output_proj_w, C, d->output_proj_b, out, C, B * Lq, C, C));
     return VLLM_OK;
 }

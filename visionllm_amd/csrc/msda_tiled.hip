@@ -325,7 +325,8 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                        hipStream_t st);   // msda_tiled4.hip
 bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
 int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16 = nullptr);   // msda_tiled7.hip
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16 = nullptr,
+                       int hinted = 0);   // msda_tiled7.hip
 int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, hipStream_t st);
 
@@ -339,7 +340,7 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
 // synchronisation.
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st, uint16_t *out16,
-                      int *wrote16)
+                      int *wrote16, int geometry)
 {
     // out16 (optional): where a caller that wants the result in bf16 would like it.  *wrote16 = 1 tells it that a pyramid
     // geometry's result went THERE (and `out` was left alone); any other geometry's result is in `out` as usual.
@@ -347,9 +348,13 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
     const int mode = msda_tiled_enabled();
     // generations 4 / 6 keep pixel / pair offsets in 32 bits; anything larger takes the generation-2 kernel
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
-    if ((mode == 1 || mode == 15 || mode == 16) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
+    // geometry (VLLM_GEO_*): what the HOST knows about the level maps.  UNKNOWN: both kernels are enqueued and the device
+    // picks (no host synchronisation; one ~5 us empty launch); PYRAMID / GENERAL: exactly one launch.
+    if ((mode == 1 || mode == 15 || mode == 16) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
+        geometry != VLLM_GEO_GENERAL) {
         if (out16 && wrote16) *wrote16 = 1; else out16 = nullptr;
-        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16)) return e;
+        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16, geometry == VLLM_GEO_PYRAMID)) return e;
+        if (geometry == VLLM_GEO_PYRAMID) return VLLM_OK;
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
     }
     if (mode >= 10 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {

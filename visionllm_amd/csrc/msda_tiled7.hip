@@ -41,7 +41,7 @@ template <int NW, int WIN, bool PROF>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
-    float *__restrict__ out, uint16_t *__restrict__ out16)
+    float *__restrict__ out, uint16_t *__restrict__ out16, int hinted)
 {
     constexpr int D = 32, PT = 4, THREADS = NW * 64, QPP = NW * 8;
     static_assert(NW * 16 >= 170, "an item has up to 170 queries");
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_box = reinterpret_cast<int *>(smem + (T6_ZPX + R + T6_SLACK) * 128);   // [3][4 levels][4]: min hl, min -hl, min wl, min -wl
 
-    if (!geometry_is_pyramid(shapes, L, Lq)) return;
+    if (!geometry_is_pyramid(shapes, L, Lq)) {
+        // hinted: the host said "pyramid" and launched no other kernel -- a stale hint must fail loudly, not leave `out` unwritten
+        if (hinted) __builtin_trap();
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned pacc[16] = {};   // (dead in the production instantiation)
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
 
 template <int NW, int WIN, bool PROF>
 int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B, int S,
-          int M, int L, int Lq, float *out, uint16_t *out16, hipStream_t st)
+          int M, int L, int Lq, float *out, uint16_t *out16, int hinted, hipStream_t st)
 {
     static int cus = 0;
     if (cus == 0) {
@@ -454,7 +458,7 @@ int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     VLLM_LAUNCH((msda_fwd_tiled7_kernel<NW, WIN, PROF>), dim3((cus / 8) * 8), dim3(NW * 64), lds, st, value, shapes, lsi, loc, attw,
-                B, S, M, L, Lq, out, out16);
+                B, S, M, L, Lq, out, out16, hinted);
     VLLM_CHECK_LAUNCH("msda_fwd_tiled7_kernel");
     return VLLM_OK;
 }
@@ -462,10 +466,10 @@ int t7_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
 }  // namespace
 
 int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16)
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted)
 {
-    if (prof) return t7_go<12, 1200, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, st);
-    return t7_go<12, 1200, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, st);
+    if (prof) return t7_go<12, 1200, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
+    return t7_go<12, 1200, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
 }
 
 int msda7_debug_counters(long *out, int n)

@@ -45,7 +45,7 @@ int attn_variant()
 {
     if (g_attn_variant < 0) {
         const char *e = getenv("VLLM_ATTN_VARIANT");
-        g_attn_variant = e ? (atoi(e) & 127) : 32;
+        g_attn_variant = e ? (atoi(e) & 0xffff) : 32;
     }
     return g_attn_variant;
 }
@@ -84,7 +84,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!strcmp(name, "dcnv3_tiled")) { const int old = vllm::dcnv3_tiled_enabled(); vllm::g_dcnv3_tiled = (value < 0 || value > 4) ? 1 : value; return old; }
     if (!strcmp(name, "msda_layer_fused")) { const int old = vllm::msda_layer_fused(); vllm::g_layer_fused = value != 0; return old; }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
-    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 127; return old; }
+    if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 0xffff; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
         if (value < 0 || value > 4 || value == 3) { vllm::set_error("gemm_variant must be 0, 1, 2 or 4"); return VLLM_EINVAL; }

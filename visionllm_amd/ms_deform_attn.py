@@ -69,7 +69,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         if value.dtype == torch.float32:
             if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
                 raise RuntimeError("ms_deform_attn_forward: all floating inputs must share the value dtype (float32)")
-            _lib.check(lib.vllm_msda_forward_f32(*args), "vllm_msda_forward_f32")
+            geo = known_geometry(spatial_shapes, Lq)   # no synchronisation: GEO_UNKNOWN unless a module / caller looked already
+            _lib.check(lib.vllm_msda_forward_f32_geo(*args[:12], geo, *args[12:]), "vllm_msda_forward_f32")
         elif value.dtype == torch.float64:
             if sampling_loc.dtype != torch.float64 or attn_weight.dtype != torch.float64:
                 raise RuntimeError("ms_deform_attn_forward: all floating inputs must share the value dtype (float64)")
@@ -246,24 +247,69 @@ def msda_layer_fused_ok(query, input_flatten, *linears, reference_points=None):
     return d_model % 64 == 0 and all(lin.weight.dtype == torch.bfloat16 and lin.bias is not None for lin in linears)
 
 
-_LEVEL_PIXELS = {}   # id(spatial_shapes) -> (weakref, tensor version, sum of H * W)
+GEO_UNKNOWN, GEO_PYRAMID, GEO_GENERAL = 0, 1, 2   # VLLM_GEO_* of include/vllm_hip.h
+_SHAPE_FACTS = {}   # id(spatial_shapes) -> (weakref, tensor version, sum of H * W, geometry)
+
+
+def _tensor_version(t):
+    """Autograd version counter, or None for tensors that have none (created under torch.inference_mode())."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def shape_facts(spatial_shapes):
+    """(sum_l H_l * W_l, geometry) of a [L, 2] shape tensor, as Python ints.
+
+    The sum is the quantity the reference's modules compare with the value length on every call (ms_deform_attn.py:100,
+    multi_scale_deform_attn.py:319, ...mask_dn.py:741) -- a host synchronisation per layer.  The same read-back tells
+    whether the level maps form an exact 2x pyramid (GEO_PYRAMID) or not (GEO_GENERAL), which lets the native operator
+    enqueue ONE kernel instead of two (vllm_msda_forward_f32_geo).  The det heads pass the SAME tensor object to every
+    encoder / decoder layer, so the result is remembered per tensor object and autograd version (an in-place change bumps
+    the version; a dead object's id can be reused, hence the weak reference): one synchronisation per forward pass instead
+    of one per layer, same check.  Tensors without a version counter (inference tensors) are read back on every call: an
+    in-place change could not be noticed."""
+    key = id(spatial_shapes)
+    ver = _tensor_version(spatial_shapes)
+    ent = _SHAPE_FACTS.get(key)
+    if ver is not None and ent is not None and ent[0]() is spatial_shapes and ent[1] == ver:
+        return ent[2], ent[3]
+    hw = spatial_shapes.detach().reshape(-1, 2).tolist()    # ONE device -> host copy
+    total = sum(int(h) * int(w) for h, w in hw)
+    h0, w0 = (int(hw[0][0]), int(hw[0][1])) if hw else (0, 0)
+    pyramid = 1 <= len(hw) <= 4 and h0 > 0 and w0 > 0 and all(
+        (int(h) << l) == h0 and (int(w) << l) == w0 for l, (h, w) in enumerate(hw))
+    geo = GEO_PYRAMID if pyramid else GEO_GENERAL
+    if ver is not None:
+        if len(_SHAPE_FACTS) >= 64:
+            _SHAPE_FACTS.clear()
+        _SHAPE_FACTS[key] = (weakref.ref(spatial_shapes), ver, total, geo)
+    return total, geo
 
 
 def level_pixels(spatial_shapes):
-    """sum_l H_l * W_l of a [L, 2] shape tensor as a Python int -- the quantity the reference's modules compare with the value
-    length on every call (ms_deform_attn.py:100, multi_scale_deform_attn.py:319, ...mask_dn.py:741), which costs a host
-    synchronisation per layer.  The det heads pass the SAME tensor object to every encoder / decoder layer, so the result is
-    remembered per tensor object and autograd version (an in-place change bumps the version; a dead object's id can be
-    reused, hence the weak reference): one synchronisation per forward pass instead of one per layer, same check."""
-    key = id(spatial_shapes)
-    ent = _LEVEL_PIXELS.get(key)
-    if ent is not None and ent[0]() is spatial_shapes and ent[1] == spatial_shapes._version:
-        return ent[2]
-    total = int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum())
-    if len(_LEVEL_PIXELS) >= 64:
-        _LEVEL_PIXELS.clear()
-    _LEVEL_PIXELS[key] = (weakref.ref(spatial_shapes), spatial_shapes._version, total)
-    return total
+    """sum_l H_l * W_l as a Python int (see shape_facts)."""
+    return shape_facts(spatial_shapes)[0]
+
+
+def known_geometry(spatial_shapes, num_queries):
+    """GEO_* for the native operator if it is already known for this tensor object WITHOUT a synchronisation (a module's
+    `level_pixels` check, or an earlier call of `remember_geometry`), else GEO_UNKNOWN.  The pyramid kernel serves the
+    encoder case only: the queries must be the cells of the maps."""
+    ver = _tensor_version(spatial_shapes)
+    ent = _SHAPE_FACTS.get(id(spatial_shapes))
+    if ver is None or ent is None or ent[0]() is not spatial_shapes or ent[1] != ver:
+        return GEO_UNKNOWN
+    if ent[3] == GEO_PYRAMID and ent[2] != num_queries:
+        return GEO_GENERAL
+    return ent[3]
+
+
+def remember_geometry(spatial_shapes):
+    """Optional, for callers of the bare operator (ms_deform_attn_forward) outside the module mirrors: one read-back now,
+    one kernel launch per call afterwards."""
+    return shape_facts(spatial_shapes)[1]
 
 
 def msda_layer_forward(query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask,
@@ -326,6 +372,9 @@ def msda_layer_prepare(query, reference_points, input_flatten, spatial_shapes, l
     out = torch.empty_like(q)
 
     def launch():
+        # by now the module mirror has run the reference's `(H * W).sum() == Len_in` check on this tensor object, so the
+        # geometry is known without another synchronisation (GEO_UNKNOWN otherwise: the device decides, two launches more)
+        desc.geometry = known_geometry(spatial_shapes, Lq)
         with torch.cuda.device(q.device):
             _lib.check(L.vllm_msda_layer_forward(ctypes.byref(desc), _lib.ptr(q), _lib.ptr(ref), _lib.ptr(x), _lib.ptr(mask),
                                                  _lib.ptr(shapes), _lib.ptr(lsi), B, Lq, S, _lib.ptr(out), _lib.ptr(ws),
