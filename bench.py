@@ -93,6 +93,11 @@ def build_msda_inputs(dev, B, seed):
             t[k] = t[k].repeat(B, *([1] * (t[k].dim() - 1))).contiguous()
         t["value"] = t["value"] + 0.05 * torch.randn(t["value"].shape, device=dev, generator=gen)
         t["loc"] = (t["loc"] + 0.002 * torch.randn(t["loc"].shape, device=dev, generator=gen)).contiguous()
+        # every det-head layer has its own value_proj, i.e. its own value tensor: the decoder-shaped calls rotate over 3
+        # buffers (3 x 307 MB > the 256 MB Infinity Cache) instead of re-reading one tensor out of the caches; the
+        # encoder-shaped call moves 1.07 GB per call anyway
+        n_buf = 3 if tag == "dec" else 1
+        t["values"] = [t["value"]] + [t["value"] + 0.01 * torch.randn(t["value"].shape, device=dev, generator=gen) for _ in range(n_buf - 1)]
         out[tag] = t
     return out
 
@@ -118,31 +123,81 @@ def event_time(fn, iters, stream=None, rounds=3):
     return float(np.median(ts))
 
 
-def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload="vitl"):
-    """Achieved vs peak of every hot kernel of the workload, each launched alone (HIP events on torch's current stream =
-    the stream the C ABI launches on) + its launches per step.  cfg: VIT or IVIT; bridge_dims: [(M, N, K), ...]."""
+NONPYR_SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]   # ceil-divided levels of an 800 x 1333 detection input
+
+
+def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload="vitl", in_step=None):
+    """Achieved vs peak of every hot kernel of the workload.  `us_per_launch` (and achieved / frac) are the IN-STEP figures
+    when `in_step` has them ({prof tag: (us per launch, launches per step)}, from vllm_prof_read over instrumented steps:
+    event-to-event time inside step(), queueing and launch gaps included); `us_per_launch_isolated` is the same launch
+    alone, back to back (HIP events on torch's current stream = the stream the C ABI launches on), which reads 3-6 % fast.
+    cfg: VIT or IVIT; bridge_dims: [(M, N, K), ...]."""
     from visionllm_amd import _lib
     from visionllm_amd import ms_deform_attn as A
     L = _lib.lib()
     st = _lib.current_stream(torch.device(dev))
+    in_step = in_step or {}
     C, H, I, NL = cfg["hidden_size"], cfg["num_attention_heads"], cfg["intermediate_size"], cfg["num_hidden_layers"]
     S = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
     D = C // H
     M = n_tiles * S
     act = 2 if cfg["hidden_act"] == "quick_gelu" else 1
     out = {}
+
+    def entry(tag, kernel, bound, work, sec_iso, n_launch, peak, unit, scale, **extra):
+        us_iso = sec_iso * 1e6
+        us = in_step[tag][0] if tag in in_step else us_iso
+        e = dict(kernel=kernel, bound=bound, achieved=work / (us * 1e-6) / scale, peak=peak, unit=unit,
+                 frac=(work / (us * 1e-6) / scale / peak) if peak else None, traffic=None, us_per_launch=us,
+                 us_per_launch_isolated=us_iso, timing="in-step (event to event inside step())" if tag in in_step else "isolated launches",
+                 launches_per_step=in_step[tag][1] if tag in in_step else n_launch)
+        e.update(extra)
+        return e
+
     # MSDA: HBM bound, algorithmic bytes = value + loc + attw + out (SURVEY 8d)
-    for tag, nm, n_launch in (("enc", "msda", MSDA["enc_layers"]), ("dec", "msda_dec", MSDA["dec_layers"])):
+    for tag, nm, n_launch, ptag in (("enc", "msda", MSDA["enc_layers"], "msda_encoder_shape"), ("dec", "msda_dec", MSDA["dec_layers"], "msda_other")):
         t = msda_in[tag]
-        f = lambda: A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)  # noqa: E731
+        vals = t["values"]
+        k = [0]
+
+        def f(t=t, vals=vals, k=k):
+            k[0] += 1
+            return A.ms_deform_attn_forward(vals[k[0] % len(vals)], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)
         f(); torch.cuda.synchronize()
         sec = event_time(f, iters)
         ab = msda_bytes(t)
-        kern = ("msda_fwd_tiled7_kernel<12 waves, 1 block per CU> (fp32, D32, pyramid items, encoder shape Lq=S=37485, B=8)"
-                if tag == "enc" else "msda_fwd_vec_kernel (fp32, D32, decoder shape Lq=900, B=8)")
-        out[nm] = dict(kernel=kern, bound="hbm", achieved=ab / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                       frac=ab / sec / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=sec * 1e6, algorithmic_bytes=ab,
-                       launches_per_step=n_launch)
+        geo = A.known_geometry(t["shapes"], t["loc"].shape[1])
+        if tag == "enc":
+            kern = {A.GEO_PYRAMID: "msda_fwd_tiled7_kernel<12 waves, 1 block per CU> (pyramid items; ONE launch: geometry known on the host)",
+                    A.GEO_GENERAL: "msda_fwd_tiled4_kernel (any-geometry LDS-tiled kernel; one launch)",
+                    A.GEO_UNKNOWN: "msda_fwd_tiled7_kernel + empty msda_fwd_tiled4_kernel launch (geometry decided on the device)"}[geo]
+            kern += " fp32, D32, encoder shape Lq=S=37485, B=8"
+            out[nm] = entry(ptag, kern, "hbm", ab, sec, n_launch, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab)
+        else:
+            # 325 MB of value + 37 MB of the rest per call; the step rotates over len(vals) value tensors (one per decoder layer,
+            # as in the det head), so the calls stream from HBM instead of re-reading one tensor from L2 / Infinity Cache
+            out[nm] = entry(ptag, "msda_fwd_vec_kernel (fp32, D32, decoder shape Lq=900, B=8)", "hbm", ab, sec, n_launch,
+                            HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
+                            note=f"value tensors rotated over {len(vals)} buffers ({len(vals) * vals[0].numel() * 4 / 1e6:.0f} MB > the 256 MB Infinity Cache)")
+    # the same operator on a NON-pyramid geometry (ceil-divided levels, what detection inputs usually give): isolated only
+    try:
+        from msda_inputs import make_inputs
+        g = make_inputs(1, MSDA["M"], MSDA["D"], NONPYR_SHAPES, MSDA["P"], mode="encoder_like", seed=3)
+        tn = {k_: torch.from_numpy(v).to(dev) for k_, v in g.items()}
+        for k_ in ("value", "loc", "attw"):
+            tn[k_] = tn[k_].repeat(IMAGES_PER_RANK, *([1] * (tn[k_].dim() - 1))).contiguous()
+        A.remember_geometry(tn["shapes"])
+        f = lambda: A.ms_deform_attn_forward(tn["value"], tn["shapes"], tn["lsi"], tn["loc"], tn["attw"], 64)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, iters)
+        tn["values"] = [tn["value"]]
+        ab = msda_bytes(tn)
+        out["msda_nonpyramid"] = entry("-", "msda_fwd_tiled4_kernel (any-geometry kernel: levels 100x167 / 50x84 / 25x42 / 13x21, B=8, Lq=S)", "hbm",
+                                       ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
+                                       note="not part of the step: the pyramid-item kernel needs exact 2x levels; this is what other geometries get")
+        del tn
+    except Exception as e:   # measurement extra: never fail the bench line for it
+        out["msda_nonpyramid"] = {"error": repr(e)}
     # attention: MFMA bound, flops = 4*H*S^2*d per tile
     qkv = torch.randn(n_tiles, S, 3, H, D, device=dev).to(torch.bfloat16)
     ao = torch.empty(n_tiles, S, H, D, dtype=torch.bfloat16, device=dev)
@@ -150,18 +205,17 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
     f(); torch.cuda.synchronize()
     sec = event_time(f, iters)
     fl = 4.0 * H * S * S * D * n_tiles
-    out["attn"] = dict(kernel=f"attn_fwd_kernel<D{D}> ({n_tiles} tiles x {H} heads x S{S})", bound="mfma", achieved=fl / sec / 1e12,
-                       peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF, traffic=None,
-                       us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=NL)
+    out["attn"] = entry("attn", f"attn_fwd_kernel<D{D}> ({n_tiles} tiles x {H} heads x S{S})", "mfma", fl, sec, NL, MFMA_BF16_PEAK_TF,
+                        "TFLOP/s", 1e12, algorithmic_flops=fl)
     del qkv, ao
-    # the four encoder GEMMs + the projector GEMMs
-    # epilogues as the encoder uses them: 3 = bias (+ LayerScale for InternViT) + residual
-    gemms = [("gemm_qkv", M, 3 * C, C, 0, NL), ("gemm_proj", M, C, C, 3, NL), ("gemm", M, I, C, act, NL), ("gemm_fc2", M, C, I, 3, NL)]
-    gemms += [(f"gemm_bridge{i}", m, n, k, 0, 1) for i, (m, n, k) in enumerate(bridge_dims)]
+    # the four encoder GEMMs + the projector GEMMs; epilogues as the encoder uses them: 3 = bias (+ LayerScale for InternViT) + residual
+    gemms = [("gemm_qkv", M, 3 * C, C, 0, NL, "gemm_qkv"), ("gemm_proj", M, C, C, 3, NL, "gemm_proj"), ("gemm", M, I, C, act, NL, "gemm_fc1"),
+             ("gemm_fc2", M, C, I, 3, NL, "gemm_fc2")]
+    gemms += [(f"gemm_bridge{i}", m, n, k, 0, 1, "-") for i, (m, n, k) in enumerate(bridge_dims)]
     has_ls = "qk_normalization" in cfg   # InternViT: LayerScale in the residual epilogue; CLIP: plain residual
     names = {"gemm": "MLP fc1 + activation", "gemm_qkv": "QKV", "gemm_proj": "attention out-proj + " + ("LayerScale + " if has_ls else "") + "residual",
              "gemm_fc2": "MLP fc2 + " + ("LayerScale + " if has_ls else "") + "residual"}
-    for nm, m, n, k, epi, n_launch in gemms:
+    for nm, m, n, k, epi, n_launch, ptag in gemms:
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
         b = torch.zeros(n, device=dev).to(torch.bfloat16)
@@ -173,10 +227,23 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         f(); torch.cuda.synchronize()
         sec = event_time(f, iters)
         fl = 2.0 * m * n * k
-        out[nm] = dict(kernel=f"gemm256_bf16_kernel ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", bound="mfma",
-                       achieved=fl / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=fl / sec / 1e12 / MFMA_BF16_PEAK_TF,
-                       traffic=None, us_per_launch=sec * 1e6, algorithmic_flops=fl, launches_per_step=n_launch)
+        out[nm] = entry(ptag, f"gemm256_bf16_kernel ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", "mfma", fl, sec, n_launch,
+                        MFMA_BF16_PEAK_TF, "TFLOP/s", 1e12, algorithmic_flops=fl)
         del x, w, b, y, res, ls
+    # norms (LayerNorm / RMSNorm, incl. InternViT's q / k norms): HBM bound, one read + one write of [M, C] bf16
+    if "norm" in in_step:
+        ab = 2.0 * M * C * 2
+        us, n = in_step["norm"]
+        out["norm"] = dict(kernel=f"norm_bf16_kernel ([{M}, {C}] bf16)", bound="hbm", achieved=ab / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS,
+                           unit="GB/s", frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, us_per_launch=us,
+                           timing="in-step (event to event inside step())", launches_per_step=n, algorithmic_bytes=ab)
+    if "qk_norm" in in_step:
+        ab = 2.0 * 2 * M * C * 2
+        us, n = in_step["qk_norm"]
+        out["qk_norm"] = dict(kernel=f"norm_bf16_kernel x 2 (q and k RMSNorm over [{M}, {C}] slabs of qkv)", bound="hbm",
+                              achieved=ab / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              traffic=None, us_per_launch=us, timing="in-step, both launches together", launches_per_step=n,
+                              algorithmic_bytes=ab)
     # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -283,80 +350,102 @@ def _respawn_under_launcher(n):
     os.execvpe(sys.executable, cmd, env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="vitl", choices=["vitl", "internvit6b"],
-                    help="vitl (default; the metric's ViT-L config) or internvit6b (BASELINE configs[2]: 5 tiles of 448^2 per "
-                         "image through InternViT-6B + pixel-shuffle + internvl_mlp projector)")
-    ap.add_argument("--msda-stream", type=int, default=0, choices=[0, 1],
-                    help="0 (default): one stream; 1: the MSDA calls on a side stream next to the ViT (cross-batch pipelining: in "
-                         "the reference the det head of a batch depends on that batch's LLM output)")
-    ap.add_argument("--allgather-lag", type=int, default=1, choices=[0, 1],
-                    help="N > 1: 1 (default) = a step's token all-gather is waited for one step later, so it overlaps the next "
-                         "step's encoder too (steady-state pipeline; everything is drained inside the timed region); 0 = waited "
-                         "for at the end of its own step")
-    ap.add_argument("--allgather", default="collective", choices=["collective", "direct"],
-                    help="token all-gather: RCCL all_gather_into_tensor (default) or batched point-to-point to all peers at once")
-    ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="0 / 1 (default): one launch sequence; k: the tiles as k chunks on k streams (measured slower)")
-    args = ap.parse_args()
+def read_in_step_profile(lib, n_steps):
+    """{tag name: (us per launch, launches per step)} from the library's in-step recorder (vllm_prof_read)."""
+    import ctypes
+    n = 32
+    us = (ctypes.c_double * n)()
+    cnt = (ctypes.c_long * n)()
+    got = lib.vllm_prof_read(us, cnt, n)
+    out = {}
+    for i in range(max(got, 0)):
+        if cnt[i] > 0:
+            out[lib.vllm_prof_tag_name(i).decode()] = (us[i] / cnt[i], cnt[i] / n_steps)
+    return out
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        _respawn_under_launcher(args.gpus)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
-    from visionllm_amd import ms_deform_attn as A
+def run_workload(args, workload, dev, rank, world, dist, dry):
+    """One workload end to end: build, warm up, time EXACTLY args.steps steps (barrier + synchronize on both sides, max over
+    ranks), phases, in-step kernel times, rooflines.  Returns the record (rank 0) or None."""
     from visionllm_amd.dist import all_gather_visual_tokens
-
-    ivit = args.workload == "internvit6b"
-    if args.encoder_chunks:
-        from visionllm_amd import vit_common
-        vit_common.set_encoder_chunks(args.encoder_chunks)
-    enc, bridge = build_intern_model(dev) if ivit else build_model(dev)
-    if ivit:
-        enc.keep_hidden_states = (-1, -2, -3)   # 49 x 262 MB otherwise; the reference reads only these
+    ivit = workload == "internvit6b"
     n_tiles = IMAGES_PER_RANK * TILES_PER_IMAGE
-    img = IVIT["image_size"] if ivit else VIT["image_size"]
-    gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    pixels = torch.randn(n_tiles, 3, img, img, device=dev, generator=gen).to(torch.bfloat16)
-    msda_in = build_msda_inputs(dev, IMAGES_PER_RANK, 200 + rank)
-    side = torch.cuda.Stream(device=dev) if args.msda_stream else None
+    cfg = IVIT if ivit else VIT
+    T = (cfg["image_size"] // cfg["patch_size"]) ** 2
+    T_out = T // 4 if ivit else T
+    if dry:
+        # plumbing mode (CPU, gloo): the kernels are stubbed out IN THE BENCH ONLY -- a step is "produce a token tensor";
+        # everything around it (respawn, rank / device mapping, process group, lagged collective + drain, phases, max over
+        # ranks, JSON) is the code the GPU run executes
+        tok_shape = (n_tiles, 8, 64)
+        enc = bridge = None
+        pixels = msda_in = None
+        A = None
+    else:
+        from visionllm_amd import _lib
+        from visionllm_amd import ms_deform_attn as A
+        if args.encoder_chunks:
+            from visionllm_amd import vit_common
+            vit_common.set_encoder_chunks(args.encoder_chunks)
+        enc, bridge = build_intern_model(dev) if ivit else build_model(dev)
+        if ivit:
+            enc.keep_hidden_states = (-1, -2, -3)   # 49 x 262 MB otherwise; the reference reads only these (SURVEY 8a, a8)
+        img = cfg["image_size"]
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        pixels = torch.randn(n_tiles, 3, img, img, device=dev, generator=gen).to(torch.bfloat16)
+        msda_in = build_msda_inputs(dev, IMAGES_PER_RANK, 200 + rank)
+        for t in msda_in.values():
+            A.remember_geometry(t["shapes"])     # one read-back now (a det head's own shape check does it), one launch per call
+    side = torch.cuda.Stream(device=dev) if (args.msda_stream and not dry) else None
+    rot = [0]
 
     def msda_calls(res):
+        if dry:
+            return
         for tag, n in (("enc", MSDA["enc_layers"]), ("dec", MSDA["dec_layers"])):
             t = msda_in[tag]
             for _ in range(n):
-                res.append(A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64))
+                rot[0] += 1
+                res.append(A.ms_deform_attn_forward(t["values"][rot[0] % len(t["values"])], t["shapes"], t["lsi"], t["loc"], t["attw"], 64))
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    class _Mark:
+        def __init__(self):
+            self.t = None
+            self.e = None if dry else torch.cuda.Event(enable_timing=True)
+
+        def record(self):
+            if dry:
+                self.t = time.perf_counter()
+            else:
+                self.e.record()
+
+        def ms_to(self, other):
+            return (other.t - self.t) * 1e3 if dry else self.e.elapsed_time(other.e)
+
+    pending = [None]
+    lag = [1]
 
     def step(marks=None):
-        """marks: optional list receiving 4 HIP events (start, ViT+projector done, all-gather done, MSDA done); with marks the
+        """marks: optional list receiving 4 marks (start, ViT+projector done, all-gather done, MSDA done); with marks the
         collective is waited for before the MSDA calls so that the three phases can be told apart."""
         res = []
-        main = torch.cuda.current_stream(dev)
-        ev = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())  # noqa: E731
+        ev = lambda: (marks.append(_Mark()), marks[-1].record())  # noqa: E731
         if marks is not None:
             ev()
+        main = None if dry else torch.cuda.current_stream(dev)
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 msda_calls(res)
-        out = enc(pixels, output_hidden_states=True)
-        tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
+        if dry:
+            tokens = torch.full(tok_shape, float(rank), dtype=torch.bfloat16)
+        else:
+            out = enc(pixels, output_hidden_states=True)
+            tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
         if marks is not None:
             ev()
         # the token all-gather (RCCL over xGMI, its own stream) overlaps the det-head MSDA kernels of this step
@@ -367,7 +456,7 @@ def main():
         if side is None:
             msda_calls(res)
         if marks is None:
-            if args.allgather_lag and world > 1:
+            if lag[0] and world > 1:
                 # software pipeline across steps: this step's collective is waited for one step later (before the next one is
                 # launched), so it overlaps the NEXT step's encoder as well; the last one is drained before the timed region ends
                 prev, pending[0] = pending[0], handle
@@ -381,84 +470,183 @@ def main():
         res.append(gathered)
         return res
 
-    pending = [None]
-
     def drain():
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
 
+    def timed(n_steps, lag_steps):
+        """EXACTLY n_steps steps between (barrier + synchronize) pairs; the last lagged collective is drained inside."""
+        lag[0] = lag_steps
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        drain()                      # (the last step's collective belongs to the timed region)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        return time.perf_counter() - t0
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
         drain()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        drain()                      # (the last step's collective belongs to the timed region)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # headline: the collective of a step is waited for INSIDE the step (lag 0: its cost is fully visible); for N > 1 the
+        # pipelined schedule (lag 1: waited for one step later, overlapping the next encoder) is timed as well, same steps
+        headline_lag = args.allgather_lag if world > 1 else 0
+        dt = timed(args.steps, headline_lag)
+        dt_alt = timed(args.steps, 1 - headline_lag) if world > 1 else None
         # per-phase times (outside the timed region): 3 instrumented steps, median per rank, max over ranks
         ph = []
         for _ in range(3):
             marks = []
             step(marks)
-            torch.cuda.synchronize()
-            ph.append([marks[i].elapsed_time(marks[i + 1]) for i in range(3)])
+            sync()
+            ph.append([marks[i].ms_to(marks[i + 1]) for i in range(3)])
         ph = np.median(np.array(ph), axis=0)
-    red = torch.tensor([dt, ph[0], ph[1], ph[2]], device=dev, dtype=torch.float64)
+        # in-step kernel times: 3 more steps with the library's recorder on (an event in front of every operator)
+        in_step = {}
+        if not dry and rank == 0:
+            from visionllm_amd import _lib
+            L = _lib.lib()
+            L.vllm_prof_enable(1)
+            for _ in range(3):
+                step()
+            in_step = read_in_step_profile(L, 3)
+            L.vllm_prof_enable(0)
+        elif not dry:
+            for _ in range(3):
+                step()       # (all ranks run the same number of collectives)
+        drain()
+    red = torch.tensor([dt, ph[0], ph[1], ph[2], dt_alt if dt_alt is not None else 0.0], device=None if dry else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     dt = float(red[0].item())
-
-    if rank == 0:
-        cfg = IVIT if ivit else VIT
-        T = (cfg["image_size"] // cfg["patch_size"]) ** 2
+    if rank != 0:
+        return None
+    rec = {
+        "value": world * IMAGES_PER_RANK * args.steps / dt,
+        "ms_per_step": dt / args.steps * 1e3,
+        "config": {"workload": ("internvit6b_448_5tiles+pixelshuffle+internvl_mlp+msda_cfg4" if ivit else
+                                "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4") + ("  [DRY RUN: kernels stubbed, CPU / gloo plumbing only]" if dry else ""),
+                   "images_per_gpu": IMAGES_PER_RANK, "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336",
+                   "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
+                   "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096",
+                   "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900 (3 rotating value buffers)",
+                   "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else ""),
+                   "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                   "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else "none"),
+                   "allgather": args.allgather, "allgather_lag_steps": headline_lag,
+                   "streams": ("vit+projector | msda (side stream; cross-batch pipelining)" if args.msda_stream else "single") +
+                              ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
+        "phases_ms": {"vit_projector": float(red[1].item()), "token_allgather": float(red[2].item()), "msda_12_calls": float(red[3].item()),
+                      "note": "3 instrumented steps after the timed region (collective waited for before the MSDA calls), median per rank, max over ranks"},
+    }
+    if world > 1:
+        alt = float(red[4].item())
+        rec["allgather_lag_alt"] = {"allgather_lag_steps": 1 - headline_lag, "value": world * IMAGES_PER_RANK * args.steps / alt,
+                                    "ms_per_step": alt / args.steps * 1e3,
+                                    "note": "the same steps with the other collective schedule (lag 1 = a step's tokens are waited for one step "
+                                            "later and overlap the next encoder; lag 0 = inside the step)"}
+    if not dry:
         bdims = ([(n_tiles * T // 4, LLM_HIDDEN, 4 * cfg["hidden_size"]), (n_tiles * T // 4, LLM_HIDDEN, LLM_HIDDEN)] if ivit else
                  [(n_tiles * T, LLM_HIDDEN, cfg["hidden_size"]), (n_tiles * T, LLM_HIDDEN, LLM_HIDDEN)])
-        rl = kernel_rooflines(dev, msda_in, n_tiles, cfg, bdims, workload=args.workload)
+        rl = kernel_rooflines(dev, msda_in, n_tiles, cfg, bdims, workload=workload, in_step=in_step)
         step_us = dt / args.steps * 1e6
         for v in rl.values():
-            v["share_of_step"] = v["launches_per_step"] * v["us_per_launch"] / step_us
-        dom = max(rl, key=lambda k: rl[k]["share_of_step"])
+            if "us_per_launch" in v:
+                v["share_of_step"] = v["launches_per_step"] * v["us_per_launch"] / step_us
+        dom = max((k for k in rl if "share_of_step" in rl[k]), key=lambda k: rl[k]["share_of_step"])
+        rec["roofline"] = {k: rl[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | \
+                          {"kernel": rl[dom]["kernel"], "share_of_step": rl[dom]["share_of_step"], "us_per_launch": rl[dom]["us_per_launch"],
+                           "timing": rl[dom]["timing"]}
+        rec["rooflines"] = rl
+        rec["in_step_us_per_launch"] = {k: round(v[0], 2) for k, v in in_step.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(ivit)
+    del enc, bridge, pixels, msda_in
+    if not dry:
+        torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="auto", choices=["auto", "vitl", "internvit6b", "both"],
+                    help="vitl: the metric's ViT-L config; internvit6b: BASELINE configs[2] (5 tiles of 448^2 per image through "
+                         "InternViT-6B + pixel-shuffle + internvl_mlp projector); both: the vitl line with the InternViT-6B record under "
+                         "the key \"internvit6b\"; auto (default): both on one GPU, vitl on several")
+    ap.add_argument("--msda-stream", type=int, default=0, choices=[0, 1],
+                    help="0 (default): one stream; 1: the MSDA calls on a side stream next to the ViT (cross-batch pipelining: in "
+                         "the reference the det head of a batch depends on that batch's LLM output)")
+    ap.add_argument("--allgather-lag", type=int, default=0, choices=[0, 1],
+                    help="N > 1, the schedule of the HEADLINE number: 0 (default) = a step's token all-gather is waited for inside the "
+                         "step; 1 = one step later (overlaps the next step's encoder; drained inside the timed region).  The other "
+                         "schedule is timed too and reported under \"allgather_lag_alt\"")
+    ap.add_argument("--allgather", default="collective", choices=["collective", "direct"],
+                    help="token all-gather: RCCL all_gather_into_tensor (default) or batched point-to-point to all peers at once")
+    ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="0 / 1 (default): one launch sequence; k: the tiles as k chunks on k streams (measured slower)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU plumbing check (no GPU, gloo): launcher respawn, rank mapping, process group, lagged collective + drain, "
+                         "phases, JSON -- with the kernels stubbed out in the bench only; the line says so and is NOT a measurement")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_launcher(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    import torch.distributed as dist
+    if args.dry_run:
+        dev = "cpu"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+        torch.cuda.set_device(local_rank)
+        dev = f"cuda:{local_rank}"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "both" if (world == 1 and not args.dry_run) else "vitl"
+    first = "internvit6b" if workload == "internvit6b" else "vitl"
+    rec = run_workload(args, first, dev, rank, world, dist, args.dry_run)
+    extra = run_workload(args, "internvit6b", dev, rank, world, dist, args.dry_run) if workload == "both" else None
+    if rank == 0:
         line = {
             "metric": "images/sec (ViT-L+projector+MSDeformAttn fwd, 1336px)",
-            "value": world * IMAGES_PER_RANK * args.steps / dt,
+            "value": rec["value"],
             "unit": "images/sec",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("internvit6b_448_5tiles+pixelshuffle+internvl_mlp+msda_cfg4" if ivit else
-                                    "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4"), "images_per_gpu": IMAGES_PER_RANK,
-                       "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336",
-                       "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
-                       "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096",
-                       "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900",
-                       "parallelism": f"dp{world}" + ("+allgather(tokens)" if world > 1 else ""),
-                       "rccl_ranks": world, "allgather": args.allgather, "allgather_lag_steps": args.allgather_lag if world > 1 else 0,
-                       "streams": ("vit+projector | msda (side stream; cross-batch pipelining)" if args.msda_stream else "single") +
-                                  ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
-            "phases_ms": {"vit_projector": float(red[1].item()), "token_allgather": float(red[2].item()), "msda_12_calls": float(red[3].item()),
-                          "note": "3 instrumented steps after the timed region (collective waited for before the MSDA calls), median per rank, max over ranks"},
-            "roofline": {k: rl[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} |
-                        {"kernel": rl[dom]["kernel"], "share_of_step": rl[dom]["share_of_step"]},
-            "rooflines": rl,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ivit)
+        line.update({k: v for k, v in rec.items() if k not in ("value", "ms_per_step")})
+        if extra is not None:
+            line["internvit6b"] = dict(extra, metric="images/sec (InternViT-6B+pixel-shuffle+internvl_mlp+MSDeformAttn fwd, 1336px; BASELINE configs[2])",
+                                       unit="images/sec", n_gpus=world, steps=args.steps, warmup=args.warmup)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

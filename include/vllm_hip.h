@@ -58,11 +58,22 @@ int vllm_device_info(char *name, int cap);
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */
 int vllm_set_option(const char *name, int value);
-/* Diagnostics (VLLM_GEMM_PROF=1 in the environment: the 8-phase GEMM's prologue / main loop / epilogue ticks + block count;
+/* Diagnostics.  Process-wide and NOT for production use: VLLM_GEMM_PROF=1 reroutes vllm_debug_counters to the GEMM for the
+ * whole process; VLLM_GEMM_TRACE (a raw device address the 8-phase GEMM writes per-block timestamps to) exists only in
+ * builds with -DVLLM_GEMM_TRACE_ENABLE, where the address is validated as device memory first.
+ * (VLLM_GEMM_PROF=1 in the environment: the 8-phase GEMM's prologue / main loop / epilogue ticks + block count;
  * "dcnv3_tiled" = 2: the DCNv3 kernel's phases; otherwise:) with "msda_tiled" = 5 / 10 / 14 / 16 the LDS-tiled MSDA kernel of that generation adds per-phase
  * shader-clock ticks to 16 device counters; this reads the current generation's into out[0..n) and clears them.  Returns the
  * number of counters written. */
 int vllm_debug_counters(long *out, int n);
+/* In-step kernel timing (measurement; process-wide, off by default).  vllm_prof_enable(1) starts a recording: every
+ * operator the library enqueues is preceded by a HIP event on its stream; vllm_prof_read waits for the last one and returns,
+ * per tag (vllm_prof_tag_name), the summed time in microseconds from each mark to the next one and the number of marks --
+ * a kernel's duration INSIDE the step, queueing and launch gaps included (bench.py's `us_per_launch`).  Both return the
+ * number of tags (read: slots needed); vllm_prof_enable(0) stops and discards. */
+int vllm_prof_enable(int on);
+int vllm_prof_read(double *us_sum, long *count, int n);
+const char *vllm_prof_tag_name(int tag);
 
 /* ------------------------------------------------------------------------------------------------
  * B3. Multi-scale deformable attention (MSDA) operator.

@@ -350,6 +350,89 @@ def gen_token_loops():
                         text_query_masks=env2["text_query_masks"].numpy())
 
 
+def gen_region_branch():
+    """The region branch of VisionLLMv2Model.forward (modeling_visionllmv2.py:609-715), executed FROM THE REFERENCE'S OWN
+    STATEMENT: the `if self.use_region_encoder:` block is cut out of the method's AST and exec'd with a stand-in ``self``
+    whose ``region_encoder`` records its arguments (all_images, all_regions, all_image_features) and returns seeded features.
+    Three input conventions: 'anyres' (list of tile stacks, the last tile is the global image), mmic data (``num_splits``:
+    several images per sample, each with its own tile stack; one region per image) and 'pad' (one tensor)."""
+    import itertools
+    path = f"{REF}/visionllmv2/model/modeling_visionllmv2.py"
+    tree = ast.parse(open(path).read())
+    fwd = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "VisionLLMv2Model":
+            fwd = next(n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == "forward")
+    blocks = [n for n in ast.walk(fwd) if isinstance(n, ast.If) and ast.unparse(n.test) == "self.use_region_encoder"]
+    assert len(blocks) == 1 and 605 <= blocks[0].lineno <= 612, [b.lineno for b in blocks]
+    mod = ast.Module(body=[blocks[0]], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    code = compile(mod, path, "exec")
+
+    C, T, reg_token_id = 32, 9, 7          # hidden size, patches per tile, <region> id
+    out = {"reg_token_id": np.array(reg_token_id)}
+
+    def run(tag, images, regions, num_splits, split_sizes, n_tiles, seed):
+        torch.manual_seed(seed)
+        hs = [torch.randn(n_tiles, 1 + T, C) for _ in range(5)]            # encoder hidden states (only the last 3 are read)
+        n_all = sum(len(r) for r in regions)
+        B, L = len(regions), 24
+        input_ids = torch.randint(100, 130, (B, L))
+        for b, r in enumerate(regions):                                    # one <region> slot per region, scattered
+            pos = torch.randperm(L)[: len(r)]
+            input_ids[b, pos] = reg_token_id
+        inputs_embeds = torch.randn(B, L, C)
+        feats = torch.randn(n_all, C)
+        seen = {}
+
+        def region_encoder(all_images, all_regions, all_image_features):
+            seen["all_images"], seen["all_regions"] = all_images.clone(), all_regions.clone()
+            seen["all_image_features"] = [f.clone() for f in all_image_features]
+            return feats
+
+        self_ = types.SimpleNamespace(use_region_encoder=True, region_encoder=region_encoder, reg_token_id=reg_token_id)
+        env = {"torch": torch, "itertools": itertools, "self": self_, "regions": regions, "images": images, "num_splits": num_splits,
+               "image_forward_outs": types.SimpleNamespace(hidden_states=tuple(hs)), "split_sizes": split_sizes,
+               "input_ids": input_ids, "inputs_embeds": inputs_embeds.clone(), "B": B, "L": L, "C": C}
+        exec(code, env)
+        print(f"region branch [{tag}]: all_images {tuple(seen['all_images'].shape)} features {tuple(seen['all_image_features'][0].shape)}"
+              f" x{len(seen['all_image_features'])}; {n_all} <region> slots")
+        out.update({f"{tag}_hidden_states": torch.stack(hs).numpy(), f"{tag}_input_ids": input_ids.numpy(),
+                    f"{tag}_inputs_embeds": inputs_embeds.numpy(), f"{tag}_region_features": feats.numpy(),
+                    f"{tag}_num_regions": np.array([len(r) for r in regions]),
+                    f"{tag}_all_images": seen["all_images"].numpy(), f"{tag}_all_regions": seen["all_regions"].numpy(),
+                    f"{tag}_all_image_features": torch.stack(seen["all_image_features"]).numpy(),
+                    f"{tag}_out_embeds": env["inputs_embeds"].numpy()})
+        if split_sizes is not None:
+            out[f"{tag}_split_sizes"] = np.array(split_sizes)
+        if isinstance(images, list):
+            out[f"{tag}_images"] = torch.cat(images, 0).numpy()
+        else:
+            out[f"{tag}_images"] = images.numpy()
+
+    H = W = 6
+    # 'anyres': 3 samples with 3 / 1 / 5 tiles and 2 / 1 / 3 regions
+    torch.manual_seed(31)
+    split_sizes = [3, 1, 5]
+    images = [torch.randn(n, 3, H, W) for n in split_sizes]
+    regions = [torch.rand(n, H, W) > 0.5 for n in (2, 1, 3)]
+    run("anyres", images, [r.float() for r in regions], None, split_sizes, sum(split_sizes), 32)
+    # mmic: sample 0 holds 2 images with 2 + 3 tiles, sample 1 holds 3 images with 1 + 2 + 2 tiles; one region per image,
+    # the last image of sample 1 has none (the reference then drops it: [:num_regions[i]])
+    num_splits = [[2, 3], [1, 2, 2]]
+    split_sizes = [5, 5]
+    images = [torch.randn(n, 3, H, W) for n in split_sizes]
+    regions = [torch.rand(2, H, W), torch.rand(2, H, W)]
+    run("mmic", images, regions, num_splits, split_sizes, sum(split_sizes), 33)
+    out["mmic_num_splits_flat"] = np.array([x for ns in num_splits for x in ns])
+    out["mmic_num_splits_len"] = np.array([len(ns) for ns in num_splits])
+    # 'pad': one tensor of 2 images, 1 / 2 regions
+    images = torch.randn(2, 3, H, W)
+    regions = [torch.rand(1, H, W), torch.rand(2, H, W)]
+    run("pad", images, regions, None, None, 2, 34)
+    np.savez_compressed(os.path.join(OUT, "region_branch.npz"), **out)
+
+
 def gen_dcnv3():
     """DCNv3 forward: the reference's pure-PyTorch twin on the inputs of its own test (ops_dcnv3/test.py:19-66, seed 3:
     N=2, 8x8, M=4, D=16, 3x3, offset_scale 2, pad 1) plus strided / dilated / non-square cases."""
@@ -558,6 +641,7 @@ if __name__ == "__main__":
     gen_msda()
     gen_msda_layer()
     gen_token_loops()
+    gen_region_branch()
     gen_dcnv3()
     gen_point_sample()
     gen_intern_vit()

@@ -5,7 +5,7 @@ Plain-torch restatement of the per-sample token loops around the LLM in VisionLL
 executing the reference's own statements (oracle/gen_golden.py::gen_token_loops):
   * emb_splice        :432-524   [EMB] query tables written behind the tool tokens (training form, [EMB] ids present)
   * text_query        :775-787   [EMB] hidden states gathered per sample into the det head's text_query + mask
-  * region_features   :655-676   'anyres': the global tile's features (no CLS) repeated per region, last three levels
+  * region_features / region_images :626-676   per region, its image's global tile ('anyres', mmic num_splits, 'pad'), last three levels
   * region_splice     :688-695   <region> slots take the region encoder's output"""
 import torch
 
@@ -44,13 +44,41 @@ def text_query(hidden_states, input_ids, emb_token_id, num_embs):
     return tq, masks
 
 
-def region_features(hidden_states, split_sizes, num_regions, levels=(-3, -2, -1)):
+def region_features(hidden_states, split_sizes, num_regions, levels=(-3, -2, -1), num_splits=None):
+    """all_image_features (:644-676).  split_sizes None: 'pad' (one image per sample); num_splits: mmic data."""
+    import itertools
     outs = []
     for lv in levels:
-        per_sample = torch.split(hidden_states[lv], split_sizes, dim=0)
-        glob = torch.stack([x[-1, 1:] for x in per_sample], 0)                       # [bs, img_len, C]
-        outs.append(torch.cat([glob[i][None].repeat_interleave(num_regions[i], dim=0) for i in range(len(split_sizes))]))
+        hs = hidden_states[lv]
+        if num_splits is not None:                                                   # :646-662
+            per_sample = torch.split(hs, split_sizes, dim=0)
+            rows = []
+            for i, (x, ns) in enumerate(zip(per_sample, num_splits)):
+                last = torch.as_tensor([c - 1 for c in itertools.accumulate(ns)], dtype=torch.long)
+                rows.append(x[last, 1:][: num_regions[i]])
+            outs.append(torch.cat(rows, 0))
+            continue
+        if split_sizes is not None:                                                  # 'anyres' :664-671
+            per_sample = torch.split(hs, split_sizes, dim=0)
+            glob = torch.stack([x[-1, 1:] for x in per_sample], 0)                   # [bs, img_len, C]
+        else:                                                                        # 'pad' :672-673
+            glob = hs[:, 1:]
+        outs.append(torch.cat([glob[i][None].repeat_interleave(num_regions[i], dim=0) for i in range(glob.shape[0])]))
     return outs
+
+
+def region_images(images, num_regions, num_splits=None):
+    """all_images (:626-643)."""
+    import itertools
+    if num_splits is not None:
+        rows = []
+        for i, (x, ns) in enumerate(zip(images, num_splits)):
+            last = torch.as_tensor([c - 1 for c in itertools.accumulate(ns)], dtype=torch.long)
+            rows.append(x[last][: num_regions[i]])
+        return torch.cat(rows, 0)
+    if isinstance(images, (list, tuple)):
+        return torch.cat([images[i][-1][None].repeat_interleave(num_regions[i], dim=0) for i in range(len(images))], 0)
+    return torch.cat([images[i][None].repeat_interleave(num_regions[i], dim=0) for i in range(len(images))], 0)
 
 
 def region_splice(inputs_embeds, input_ids, reg_token_id, region_feats):

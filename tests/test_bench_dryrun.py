@@ -1,0 +1,43 @@
+"""bench.py's multi-rank plumbing without a GPU: `python bench.py --gpus 2 --dry-run` re-executes itself
+under torch.distributed.run (127.0.0.1), initialises the process group (gloo here, nccl = RCCL on the GPU box), runs the lagged
+token all-gather with its drain, the phase marks, the max-over-ranks reduction and prints ONE JSON line from rank 0 -- the code
+path of the real run with the kernels stubbed out in the bench only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_respawns_and_runs_two_ranks_on_cpu():
+    rec = _run("--gpus", "2")
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    cfg = rec["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["backend"] == "gloo" and cfg["parallelism"] == "dp2+allgather(tokens)"
+    assert "DRY RUN" in cfg["workload"]                      # a plumbing line must never pass for a measurement
+    # headline = the collective waited for inside its step; the pipelined schedule is reported next to it
+    assert cfg["allgather_lag_steps"] == 0 and rec["allgather_lag_alt"]["allgather_lag_steps"] == 1
+    assert rec["value"] > 0 and rec["allgather_lag_alt"]["value"] > 0
+    assert set(rec["phases_ms"]) >= {"vit_projector", "token_allgather", "msda_12_calls"}
+    assert "rooflines" not in rec and "cpu_baseline" not in rec
+
+
+def test_bench_dry_run_single_rank_and_direct_allgather():
+    rec = _run()
+    assert rec["n_gpus"] == 1 and rec["config"]["rccl_ranks"] == 1 and "allgather_lag_alt" not in rec
+    rec = _run("--gpus", "2", "--allgather", "direct", "--allgather-lag", "1")
+    assert rec["config"]["allgather"] == "direct" and rec["config"]["allgather_lag_steps"] == 1
+    assert rec["allgather_lag_alt"]["allgather_lag_steps"] == 0

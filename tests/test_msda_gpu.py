@@ -412,12 +412,17 @@ def _load_layer(g, prefix, mod):
     return mod.to(DEV).eval()
 
 
-def _bf16_close(out, ref, what):
-    """bf16 modules: parameters and activations are rounded to bf16 (8 significand bits) at four linears; the fp32
-    reference on the UNROUNDED parameters is matched to a few bf16 ulp of the output scale."""
-    err = (out.float().cpu() - torch.from_numpy(ref).float()).abs()
-    scale = float(np.abs(ref).max())
-    assert err.max().item() <= 4e-2 * scale and err.mean().item() <= 6e-3 * scale, (what, err.max().item(), err.mean().item(), scale)
+def _bf16_vs_reference_arithmetic(fused, composed, ref64, what):
+    """bf16 modules against the reference module's fp64 output (fixture).  The yardstick is the REFERENCE'S OWN bf16
+    arithmetic -- torch bf16 linears / softmax / location math around the fp32 operator, which is what the reference module
+    computes in bf16 and what our mirror's composed path runs (`composed`, taken under enable_grad so that the fused layer is
+    bypassed): the fused native layer keeps every internal tensor in fp32 and must not be further from the truth than that,
+    in RMS (x 1.05) and in the worst element (x 2: two different roundings of the same quantity)."""
+    ref = torch.from_numpy(ref64).double()
+    ef, ec = (fused.double().cpu() - ref).abs(), (composed.double().cpu() - ref).abs()
+    rms_f, rms_c = float((ef ** 2).mean().sqrt()), float((ec ** 2).mean().sqrt())
+    assert rms_f <= 1.05 * rms_c, (what, rms_f, rms_c)
+    assert float(ef.max()) <= 2.0 * float(ec.max()), (what, float(ef.max()), float(ec.max()))
 
 
 @pytest.mark.parametrize("tag", ["unipose_ref2", "unipose_ref4", "unipose_ref4_norm"])
@@ -432,8 +437,10 @@ def test_unipose_module_vs_reference_module(tag):
         np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
         mb = mod.to(torch.bfloat16)                             # bf16: the fused native layer (one C call)
         ob = mb(args[0].bfloat16(), args[1], args[2].bfloat16(), *args[3:])
+    with torch.enable_grad():                                   # trainable parameters -> composed path (torch bf16 linears)
+        oc = mb(args[0].bfloat16(), args[1], args[2].bfloat16(), *args[3:]).detach()
     assert ob.dtype == torch.bfloat16
-    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+    _bf16_vs_reference_arithmetic(ob, oc, g[f"{tag}.out_f64"], tag)
 
 
 @pytest.mark.parametrize("tag", ["mmcv_ref2", "mmcv_ref4"])
@@ -449,7 +456,9 @@ def test_mmcv_module_vs_reference_module(tag):
         out = mod(q, value=src, query_pos=pos, **kw)
         np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
         ob = mod.to(torch.bfloat16)(q.bfloat16(), value=src.bfloat16(), query_pos=pos.bfloat16(), **kw)
-    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+    with torch.enable_grad():
+        oc = mod(q.bfloat16(), value=src.bfloat16(), query_pos=pos.bfloat16(), **kw).detach()
+    _bf16_vs_reference_arithmetic(ob, oc, g[f"{tag}.out_f64"], tag)
 
 
 @pytest.mark.parametrize("tag", ["gdino_ref2", "gdino_ref4"])
@@ -468,7 +477,10 @@ def test_grounding_dino_module_vs_reference_module(tag):
         np.testing.assert_allclose(aw.cpu().numpy(), g[f"{tag}.attw_f32"], rtol=2e-5, atol=2e-6)
         ob, _ = mod.to(torch.bfloat16)(_t(g[f"{tag}.query"]).bfloat16(), encoder_hidden_states=_t(g[f"{tag}.src"]).bfloat16(),
                                        position_embeddings=_t(g[f"{tag}.pos"]).bfloat16(), **kw)
-    _bf16_close(ob, g[f"{tag}.out_f64"], tag)
+    with torch.enable_grad():
+        oc, _ = mod(_t(g[f"{tag}.query"]).bfloat16(), encoder_hidden_states=_t(g[f"{tag}.src"]).bfloat16(),
+                    position_embeddings=_t(g[f"{tag}.pos"]).bfloat16(), **kw)
+    _bf16_vs_reference_arithmetic(ob, oc.detach(), g[f"{tag}.out_f64"], tag)
 
 
 def test_compat_shims_module_name_and_mmcv_ext():
@@ -703,6 +715,27 @@ def test_fused_layer_vs_oracle(shapes, Lq, ref_dim, four_d):
     # internal tensors are fp32, so we must be at least as close to the fp64 truth as the reference's bf16 arithmetic
     assert err <= max(err_ref * 1.05, 4e-3), (err, err_ref)
     assert np.abs(o - truth).max() <= 2e-2 * np.abs(truth).max()
+
+
+def test_fused_layer_cfg4_batch8_vs_oracle_every_image():
+    """The fused layer at the shape bench.py TIMES it (BASELINE configs[3]: 168^2 / 84^2 / 42^2 / 21^2, B = 8, Lq = S = 37 485,
+    d_model 256, 8 heads): EPI_MSDA query GEMM at M = 299 880, bf16 operator output, 1200-pixel arena with late levels.
+    fp64 oracle per image on the CPU; every image is compared on its own (VERDICT r2 weak #1)."""
+    mod, q, ref, src, ss, lsi, mask = _layer_case(8, CFG4_SHAPES, None, 2, 0, seed=404)
+    with torch.no_grad():
+        out = mod(q, ref, src, ss, lsi, mask)
+        again = mod(q, ref, src, ss, lsi, mask)
+    assert torch.equal(out, again)
+    for b in range(8):
+        sl = slice(b, b + 1)
+        mb = None if mask is None else mask[sl]
+        truth, ref_bf16 = _layer_truth(mod, q[sl], ref[sl], src[sl], ss, lsi, mb)
+        o = out[sl].double().cpu().numpy()
+        rms = np.sqrt((truth ** 2).mean())
+        err = np.sqrt(((o - truth) ** 2).mean()) / rms
+        err_ref = np.sqrt(((ref_bf16 - truth) ** 2).mean()) / rms
+        assert err <= max(err_ref * 1.05, 4e-3), (b, err, err_ref)
+        assert np.abs(o - truth).max() <= 2e-2 * np.abs(truth).max(), b
 
 
 @pytest.mark.parametrize("shapes,Lq,ref_dim,four_d,M", [

@@ -57,9 +57,14 @@ def test_text_query_vs_reference_fixture_and_random_cases():
     assert torch.equal(tq.cpu(), ref) and torch.equal(masks.cpu(), rm)
     assert S.gather_emb_hidden_states(hs.to(DEV), torch.zeros_like(ids).to(DEV), E0, NE) == (None, None)
     bad = ids.clone()
-    bad[0, 0] = E0                                   # a lone [EMB] token: not a whole patch (the reference's reshape fails)
+    bad[1, 0] = E0                                   # whole patches + a stray [EMB] token (the reference's reshape fails)
     with pytest.raises(RuntimeError):
         S.gather_emb_hidden_states(hs.to(DEV), bad.to(DEV), E0, NE)
+    lone = ids.clone()
+    lone[0, 0] = E0                                  # a sample with ONLY a stray token: num_patches == 0, skipped by the reference (:783-786)
+    tq2, m2 = S.gather_emb_hidden_states(hs.to(DEV), lone.to(DEV), E0, NE)
+    r2, rm2 = T.text_query(hs, lone, E0, NE)
+    assert torch.equal(tq2.cpu(), r2) and torch.equal(m2.cpu(), rm2)
 
 
 def test_region_feature_gather_and_region_splice_vs_oracle():
@@ -105,3 +110,51 @@ def test_emb_splice_random_vs_oracle_and_errors():
     ids[0, L - 3] = 450                               # a tool token too close to the end of the sequence
     with pytest.raises(RuntimeError):
         S.splice_emb_tokens(ids.to(DEV), emb.to(DEV).clone(), {k: v.to(DEV) for k, v in tables.items()}, E0, NE, NG, gen_tools=(454,))
+
+
+def test_region_branch_vs_reference_fixture():
+    """Region branch (modeling_visionllmv2.py:609-715) against the fixture made by executing the reference's statement:
+    image / feature selection for 'anyres', mmic (num_splits) and 'pad' inputs, and the <region> splice -- bit-exact."""
+    from test_oracle_tokens import _region_case
+    g = load_golden("region_branch.npz")
+    for tag in ("anyres", "mmic", "pad"):
+        hs, images, split_sizes, num_regions, num_splits = _region_case(g, tag)
+        hs_dev = [h.to(torch.bfloat16).to(DEV) for h in hs]
+        feats = S.gather_region_image_features(hs_dev, split_sizes, num_regions, num_splits=num_splits)
+        want = torch.from_numpy(g[f"{tag}_all_image_features"]).to(torch.bfloat16)
+        assert torch.equal(torch.stack(feats).cpu(), want), tag
+        imgs = [x.to(DEV) for x in images] if isinstance(images, list) else images.to(DEV)
+        assert torch.equal(S.gather_region_images(imgs, num_regions, num_splits).cpu(), torch.from_numpy(g[f"{tag}_all_images"])), tag
+        emb = torch.from_numpy(g[f"{tag}_inputs_embeds"]).to(torch.bfloat16).to(DEV)
+        rf = torch.from_numpy(g[f"{tag}_region_features"]).to(torch.bfloat16).to(DEV)
+        out = S.splice_region_tokens(emb, torch.from_numpy(g[f"{tag}_input_ids"]).to(DEV), int(g["reg_token_id"]), rf)
+        # (bf16-rounded inputs: rows are copies, so rounding commutes with the reference's x * (1 - m) + t * m)
+        want = torch.from_numpy(g[f"{tag}_out_embeds"]).to(torch.bfloat16)
+        got = out.cpu()
+        ids = torch.from_numpy(g[f"{tag}_input_ids"])
+        slot = ids == int(g["reg_token_id"])
+        assert torch.equal(got[~slot], want[~slot]) and torch.equal(got[slot], rf.cpu()), tag
+
+
+def test_token_loops_refuse_to_cut_gradients():
+    """the native row mover has no backward -- inputs that require grad raise instead of losing it."""
+    C = 64
+    emb = torch.randn(1, 8, C, device=DEV, dtype=torch.bfloat16)
+    ids = torch.tensor([[5, 1, 2, 3, 4, 9, 9, 9]], device=DEV)
+    table = torch.randn(2, C, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.splice_emb_tokens(ids, emb.clone(), {5: table}, 100, 2)
+    with torch.no_grad():
+        S.splice_emb_tokens(ids, emb.clone(), {5: table}, 100, 2)
+    hs = torch.randn(1, 8, C, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.gather_emb_hidden_states(hs, ids, 1, 2)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.splice_region_tokens(emb.clone(), ids, 9, torch.randn(3, C, device=DEV, dtype=torch.bfloat16, requires_grad=True))
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.gather_region_image_features([torch.randn(2, 5, C, device=DEV, dtype=torch.bfloat16, requires_grad=True)] * 3, [2], [1])
+    # a sample with fewer stray [EMB] tokens than one patch is skipped (the reference's num_patches == 0), not an error
+    ids2 = torch.tensor([[1, 2, 7, 7, 7, 7, 7, 7], [1, 7, 7, 7, 7, 7, 7, 7]], device=DEV)
+    hs2 = torch.randn(2, 8, C, device=DEV, dtype=torch.bfloat16)
+    tq, masks = S.gather_emb_hidden_states(hs2, ids2, 1, 2)
+    assert tq.shape == (2, 1, 2, C) and masks.tolist() == [[True], [False]] and bool((tq[1] == 0).all())

@@ -1,6 +1,9 @@
 """gemm256 block timeline (VLLM_GEMM_TRACE): per block {start, end} in 100 MHz s_memrealtime ticks + HW_ID -> per CU: busy time
 inside blocks, gaps between consecutive blocks (block turnover: drain of the old block's stores, LDS / register release, launch
-of the next 8 waves), first start / last end against the kernel's duration."""
+of the next 8 waves), first start / last end against the kernel's duration.
+The trace path is compiled only into a debug build of the library:
+    make -C visionllm_amd/csrc OUT=../_build_trace EXTRA=-DVLLM_GEMM_TRACE_ENABLE -j8
+    VLLM_HIP_LIB=$PWD/visionllm_amd/_build_trace/libvllm_hip.so python tools/trace_gemm256.py"""
 import os, sys, collections, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 trace = torch.zeros(8192 * 3, dtype=torch.int64, device="cuda")

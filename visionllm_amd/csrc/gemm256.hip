@@ -510,7 +510,33 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     a.res_init = (epi == EPI_RESIDUAL && a.variant256 != 5 && !res_init_disabled() && a.N % 8 == 0 && a.N >= 8 &&
                   a.ldr % 8 == 0 && aligned16(a.res)) ? 1 : 0;
     { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
-    { static unsigned long long *const tr = [] { const char *e = getenv("VLLM_GEMM_TRACE"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : (unsigned long long *)nullptr; }(); a.trace = tr; }
+    // VLLM_GEMM_TRACE names a raw device address every block writes 24 bytes to: debug builds only (-DVLLM_GEMM_TRACE_ENABLE,
+    // tools/trace_gemm256.py builds its own library); the address is checked to be device memory of at least the size the
+    // kernel can write before it is trusted.  A release build ignores the variable.
+#ifdef VLLM_GEMM_TRACE_ENABLE
+    {
+        static unsigned long long *const tr = [] {
+            const char *e = getenv("VLLM_GEMM_TRACE");
+            unsigned long long *p = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr;
+            if (p) {
+                hipPointerAttribute_t at;
+                void *base = nullptr;
+                size_t size = 0;
+                const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice &&
+                                hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p) == hipSuccess &&
+                                (char *)base + size >= (char *)p + 3 * 8192 * sizeof(unsigned long long);
+                if (!ok) {
+                    fprintf(stderr, "libvllm_hip: VLLM_GEMM_TRACE=%s is not a device buffer of 3 x 8192 uint64 -- ignored\n", e);
+                    p = nullptr;
+                }
+            }
+            return p;
+        }();
+        a.trace = tr;
+    }
+#else
+    a.trace = nullptr;
+#endif
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
     // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
     auto rounds_cost = [&](long rows, int mt_rows) {

@@ -51,6 +51,16 @@ int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled"
 
 int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st);
 
+// In-step kernel timing (vllm_prof_enable / vllm_prof_read): when enabled, the orchestrators record a HIP event in front of
+// every operator they enqueue; the time from one mark to the next is attributed to the first one's tag, so a kernel is
+// charged its duration INSIDE the step (queueing behind its predecessor and the gap to its successor included) -- what a
+// step costs, not what the kernel does alone.  Disabled (the default) a mark is one load and a branch.
+enum ProfTag : int { PT_END = 0, PT_EMBED, PT_NORM, PT_QKV, PT_QKNORM, PT_ATTN, PT_PROJ, PT_FC1, PT_FC2, PT_BRIDGE_GEMM, PT_BRIDGE_OTHER,
+                     PT_MSDA_ENC, PT_MSDA_OTHER, PT_MSDA_LAYER, PT_COUNT };
+extern int g_prof_on;
+void prof_mark_slow(int tag, hipStream_t st);
+inline void prof_mark(int tag, hipStream_t st) { if (g_prof_on) prof_mark_slow(tag, st); }
+
 inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint16_t *W, int ldw, const uint16_t *bias,
                 uint16_t *Y, int ldy, int M, int N, int K, const uint16_t *scale = nullptr, const uint16_t *res = nullptr,
                 int ldr = 0, int P = 0, int xP = 0)

@@ -24,6 +24,7 @@
 // Roofline: HBM-bound on paper (11 flop/B); in practice limited by the 64 B/clk/CU vector-L1 path because the
 // gathered bytes are 18x the compulsory bytes (DESIGN.md section "MSDA").
 #include "common.hpp"
+#include "kernels.hpp"
 #include "msda_sample.hpp"
 
 namespace vllm {
@@ -542,11 +543,19 @@ extern "C" int vllm_msda_forward_f32_geo(const float *value, const int64_t *shap
     if ((long)B * Lq == 0) return VLLM_OK;
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc))   // encoder self-attention shape: LDS-tiled kernel
-        return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, nullptr, nullptr, geometry);
-    if (vec_ok(D, 4, L, P, value, out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0)
-        return dispatch_vec<false>(D / 4, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
-    return launch_generic_fwd<float>(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, st);
+    int rc;
+    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc)) {   // encoder self-attention shape: LDS-tiled kernel
+        prof_mark(PT_MSDA_ENC, st);
+        rc = msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, nullptr, nullptr, geometry);
+    } else {
+        prof_mark(PT_MSDA_OTHER, st);
+        if (vec_ok(D, 4, L, P, value, out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0)
+            rc = dispatch_vec<false>(D / 4, value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st);
+        else
+            rc = launch_generic_fwd<float>(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, st);
+    }
+    prof_mark(PT_END, st);
+    return rc;
 }
 
 extern "C" int vllm_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,

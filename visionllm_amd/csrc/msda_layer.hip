@@ -241,6 +241,7 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     float *value = (float *)(ws + w.value), *off = (float *)(ws + w.off), *lg = (float *)(ws + w.logit);
     float *opout = (float *)(ws + w.opout);
     uint16_t *opb = (uint16_t *)(ws + w.opout_bf16);
+    prof_mark(PT_MSDA_LAYER, st);
     // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D]
     TRY(gemm(st, EPI_F32, input_flatten, C, d->value_proj_w, C, d->value_proj_b, (uint16_t *)value, C, B * S, C, C, nullptr,
              (const uint16_t *)padding_mask));
@@ -271,5 +272,6 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     if (!(where && d->geometry == VLLM_GEO_PYRAMID))
         TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
     TRY(gemm(st, EPI_BIAS, opb, C, d->output_proj_w, C, d->output_proj_b, out, C, B * Lq, C, C));
+    prof_mark(PT_END, st);
     return VLLM_OK;
 }

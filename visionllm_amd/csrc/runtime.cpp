@@ -104,6 +104,58 @@ extern "C" int vllm_debug_counters(long *out, int n)
     const int mode = vllm::msda_tiled_enabled();
     return mode >= 15 ? vllm::msda7_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
 }
+// ---- in-step kernel timing ----------------------------------------------------------------------------------------
+#include <vector>
+#include <mutex>
+namespace vllm {
+int g_prof_on = 0;
+namespace {
+std::mutex g_prof_mu;
+std::vector<hipEvent_t> g_prof_pool;            // events, reused across read-outs
+std::vector<int> g_prof_tags;                   // tag of mark i (event i)
+}
+void prof_mark_slow(int tag, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const size_t i = g_prof_tags.size();
+    if (i >= (1u << 20)) return;                // bounded: a forgotten vllm_prof_enable(1) must not eat the host's memory
+    if (i >= g_prof_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_prof_pool.push_back(e);
+    }
+    if (hipEventRecord(g_prof_pool[i], st) == hipSuccess) g_prof_tags.push_back(tag);
+}
+}  // namespace vllm
+static const char *const kProfNames[vllm::PT_COUNT] = {"end", "embed", "norm", "gemm_qkv", "qk_norm", "attn", "gemm_proj", "gemm_fc1",
+                                                        "gemm_fc2", "gemm_bridge", "bridge_other", "msda_encoder_shape", "msda_other",
+                                                        "msda_layer"};
+extern "C" int vllm_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(vllm::g_prof_mu);
+    vllm::g_prof_tags.clear();
+    vllm::g_prof_on = on != 0;
+    return vllm::PT_COUNT;
+}
+extern "C" const char *vllm_prof_tag_name(int tag) { return tag >= 0 && tag < vllm::PT_COUNT ? kProfNames[tag] : ""; }
+extern "C" int vllm_prof_read(double *us_sum, long *count, int n)
+{
+    if (!us_sum || !count || n < vllm::PT_COUNT) { vllm::set_error("vllm_prof_read: need %d slots", (int)vllm::PT_COUNT); return VLLM_EINVAL; }
+    std::lock_guard<std::mutex> lk(vllm::g_prof_mu);
+    for (int i = 0; i < n; ++i) { us_sum[i] = 0.0; count[i] = 0; }
+    const size_t m = vllm::g_prof_tags.size();
+    if (m && hipEventSynchronize(vllm::g_prof_pool[m - 1]) != hipSuccess) { vllm::set_error("vllm_prof_read: event wait failed"); return VLLM_ELAUNCH; }
+    for (size_t i = 0; i + 1 < m; ++i) {
+        const int tag = vllm::g_prof_tags[i];
+        if (tag == vllm::PT_END) continue;      // the gap between two C calls belongs to the host, not to a kernel
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, vllm::g_prof_pool[i], vllm::g_prof_pool[i + 1]) != hipSuccess) continue;
+        us_sum[tag] += (double)ms * 1e3;
+        count[tag] += 1;
+    }
+    vllm::g_prof_tags.clear();
+    return vllm::PT_COUNT;
+}
 extern "C" int vllm_abi_version(void) { return VLLM_ABI_VERSION; }
 extern "C" const char *vllm_last_error(void) { return vllm::g_err; }
 extern "C" int vllm_device_info(char *name, int cap)

@@ -88,11 +88,13 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
 
     // ---- embeddings: im2col gather -> GEMM (+bias +pos, rows scattered past CLS) ; CLS rows ----
     uint16_t *emb = clip ? hmid : state(0);   // CLIP: pre_layrnorm produces hidden_states[0]
+    prof_mark(PT_EMBED, st);
     TRY(im2col_launch(pixels, d->pixel_is_f32, col, n, d->image, d->patch, d->kpad, st));
     TRY(gemm(st, EPI_EMBED, col, d->kpad, d->patch_w, d->kpad, d->patch_b, emb, C, n * P, C, d->kpad, nullptr, d->pos, C, P));
     TRY(cls_rows_launch(d->cls, d->pos, emb, n, S, C, st));
     if (clip) {
         VLLM_REQUIRE(d->pre_ln_w && d->pre_ln_b, "vit: CLIP needs pre_layrnorm");
+        prof_mark(PT_NORM, st);
         TRY(norm_bf16_launch(false, emb, C, d->pre_ln_w, d->pre_ln_b, state(0), C, M, C, d->eps, st));
     }
 
@@ -102,8 +104,11 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         uint16_t *hout = state(i + 1);
         VLLM_REQUIRE(L.norm1_w && L.qkv_w && L.proj_w && L.norm2_w && L.fc1_w && L.fc2_w, "vit: layer %d parameters missing", i);
         // attention block
+        prof_mark(PT_NORM, st);
         TRY(norm_bf16_launch(!clip, h, C, L.norm1_w, L.norm1_b, xn, C, M, C, d->eps, st));
+        prof_mark(PT_QKV, st);
         TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C));
+        if (L.q_norm_w || L.k_norm_w) prof_mark(PT_QKNORM, st);
         if (L.q_norm_w) TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st));
         if (L.k_norm_w) TRY(norm_bf16_launch(true, qkv + C, 3 * C, L.k_norm_w, nullptr, qkv + C, 3 * C, M, C, d->eps, st));
         {
@@ -114,14 +119,20 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
             a.q_hs = a.k_hs = a.v_hs = D;
             a.B = n; a.S = S; a.H = H; a.nqt = 0;
             a.scale_log2e = scale * 1.4426950408889634f;
+            prof_mark(PT_ATTN, st);
             TRY(attn_fwd_launch(a, D, st));
         }
+        prof_mark(PT_PROJ, st);
         TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C));
         // MLP block
+        prof_mark(PT_NORM, st);
         TRY(norm_bf16_launch(!clip, hmid, C, L.norm2_w, L.norm2_b, xn, C, M, C, d->eps, st));
+        prof_mark(PT_FC1, st);
         TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C));
+        prof_mark(PT_FC2, st);
         TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C));
     }
+    prof_mark(PT_END, st);
     return VLLM_OK;
 }
 
@@ -170,12 +181,14 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
         const int hw = (int)(sqrtf((float)T_in) + 0.5f);
         VLLM_REQUIRE(hw * hw == T_in && hw % 2 == 0, "bridge: pixel_shuffle needs an even square token grid (T=%d)", T_in);
         uint16_t *shuf = (uint16_t *)(ws + w.a);
+        prof_mark(PT_BRIDGE_OTHER, st);
         TRY(pixel_shuffle_launch(hidden, (long)S * C, C, d->skip_cls ? 1 : 0, shuf, n, hw, C, st));
         x = shuf; ldx = Cin; xP = 0; rows = (long)n * (T_in / 4);
     }
     if (d->kind == VLLM_BRIDGE_INTERNVL_MLP) {
         VLLM_REQUIRE(d->ln_w && d->ln_b, "bridge: internvl_mlp needs LayerNorm parameters");
         uint16_t *ln = (uint16_t *)(ws + w.b);
+        prof_mark(PT_BRIDGE_OTHER, st);
         if (xP == 0) {
             TRY(norm_bf16_launch(false, x, ldx, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st));
         } else {
@@ -195,9 +208,11 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
         const bool last = i == d->depth - 1;
         uint16_t *y = last ? out : tmp[i & 1];
         // GELU sits between Linear i and Linear i+1 -> fused into Linear i's epilogue
+        prof_mark(PT_BRIDGE_GEMM, st);
         TRY(gemm(st, last ? EPI_BIAS : EPI_GELU, x, ldx, d->w[i], K, d->b[i], y, Cout, (int)rows, Cout, K, nullptr, nullptr,
                  0, 0, i == 0 ? xP : 0));
         x = y; ldx = Cout; K = Cout;
     }
+    prof_mark(PT_END, st);
     return VLLM_OK;
 }

@@ -58,8 +58,8 @@ def _copy_rows(src, src_idx, dst, dst_idx, n):
 
 
 def splice_emb_tokens(input_ids, inputs_embeds, tool_tables, emb_token_id, num_embs, num_embs_gen=None, gen_tools=()):
-    """[EMB] splice (modeling_visionllmv2.py:425-527), the training / prefill form in which the [EMB] tokens are already
-    present in ``input_ids`` (gap_len = num_embs): behind every tool token the next ``num_embs`` rows of ``inputs_embeds``
+    """[EMB] splice (modeling_visionllmv2.py:425-527), the form in which the [EMB] tokens are already present in
+    ``input_ids`` (gap_len = num_embs: prefill of a prompt that carries them; FORWARD ONLY -- raises when an input requires grad): behind every tool token the next ``num_embs`` rows of ``inputs_embeds``
     are REPLACED by that tool's learned query table and the ids by the [EMB] id range.
 
     ``tool_tables``: ordered ``{tool_token_id: table [num_embs, C]}`` in the reference's order of application (det, seg,
@@ -68,6 +68,7 @@ def splice_emb_tokens(input_ids, inputs_embeds, tool_tables, emb_token_id, num_e
     (input_ids, inputs_embeds): ids as a new tensor, embeddings modified IN PLACE.  A table that would run past the end of
     the sequence raises (the reference's torch.stack of unequal lengths does)."""
     B, L, C = inputs_embeds.shape
+    _no_grad_path("splice_emb_tokens", inputs_embeds, *tool_tables.values())
     ids = input_ids.clone()
     flat = inputs_embeds.view(B * L, C)
     for tool_id, table in tool_tables.items():
@@ -95,6 +96,7 @@ def gather_emb_hidden_states(hidden_states, input_ids, emb_token_id, num_embs):
     [EMB] token is present.  The reference loops over the batch; here the k-th selected token of sample b goes to row
     b * max_patches * num_embs + k in one native row copy (one host read of the patch counts, as the reference's .max())."""
     B, L, C = hidden_states.shape
+    _no_grad_path("gather_emb_hidden_states", hidden_states)
     sel = (input_ids >= emb_token_id) & (input_ids <= emb_token_id + num_embs - 1)
     counts = sel.sum(-1)
     total = int(counts.sum())
@@ -108,7 +110,9 @@ def gather_emb_hidden_states(hidden_states, input_ids, emb_token_id, num_embs):
         return out, masks
     rank = sel.cumsum(-1) - 1                                                   # position of a selected token within its sample
     keep = sel & (rank < (num_patches * num_embs)[:, None])                     # (the reference's reshape(-1, num_embs, C) needs whole patches)
-    if bool((counts % num_embs != 0).any()):
+    # a sample with 0 < count < num_embs is SKIPPED by the reference (num_patches == 0, :783-786); one with whole patches
+    # plus a remainder fails its reshape(-1, num_embs, C)
+    if bool(((counts % num_embs != 0) & (num_patches > 0)).any()):
         raise RuntimeError("gather_emb_hidden_states: a sample's [EMB] tokens are not a whole number of patches")
     src = torch.nonzero(keep.reshape(-1), as_tuple=False).reshape(-1)
     b_of = src // L
@@ -117,20 +121,89 @@ def gather_emb_hidden_states(hidden_states, input_ids, emb_token_id, num_embs):
     return out, masks
 
 
-def gather_region_image_features(hidden_states, split_sizes, num_regions, levels=(-3, -2, -1)):
-    """Region branch, feature selection (modeling_visionllmv2.py:655-676, 'anyres' input): for every region of sample i the
-    GLOBAL tile's features (the last split of the sample) without CLS, at the last three encoder levels.
-    hidden_states: indexable of [n_tiles, 1 + T, C] bf16; -> list of [n_all_regions, T, C] (one native row gather per level)."""
+def _no_grad_path(what, *tensors):
+    """The native row mover has no backward: refuse to cut a gradient silently (the reference trains emb_embeddings_*
+    through the [EMB] splice, back-propagates the det-head loss through the [EMB] hidden states into the LLM
+    (modeling_visionllmv2.py:775-787) and the region features into the region encoder)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError(f"{what}: forward-only (inference / prefill) -- an input requires grad; run it under "
+                           "torch.no_grad() or keep the reference's torch indexing for training")
+
+
+def region_tile_index(split_sizes, num_regions, num_splits=None, n_images=None):
+    """Which tile (row of the concatenated tile batch) feeds each region, as a Python list -- the index arithmetic of the
+    reference's three input conventions (modeling_visionllmv2.py:626-676):
+      * 'anyres' (``split_sizes``: tiles per sample, ``num_splits`` None): the LAST tile of the sample (the global image),
+        once per region of the sample;
+      * mmic data (``num_splits``: per sample, tiles per image): the global tile of each image (cumulative sums - 1), the
+        first ``num_regions[i]`` of them (one region per image);
+      * 'pad' (``split_sizes`` None): image i itself, once per region.
+    ``len(split_sizes)`` (or ``n_images``) may be a multiple of ``len(num_regions)``: generate() with num_beams > 1 (:617-621)."""
+    num_regions = [int(n) for n in num_regions]
+    n_samples = len(split_sizes) if split_sizes is not None else int(n_images)
+    if len(num_regions) == 0 or n_samples % len(num_regions) != 0:
+        raise RuntimeError(f"region_tile_index: {n_samples} samples vs {len(num_regions)} region lists")
+    num_regions = num_regions * (n_samples // len(num_regions))
+    tiles = []
+    if split_sizes is None:
+        for i, n in enumerate(num_regions):
+            tiles += [i] * n
+        return tiles
+    split_sizes = [int(x) for x in split_sizes]
+    if any(x <= 0 for x in split_sizes):
+        raise RuntimeError(f"region_tile_index: every sample needs at least one tile (split_sizes = {split_sizes})")
+    off = 0
+    for i, (n_tiles, n) in enumerate(zip(split_sizes, num_regions)):
+        if num_splits is not None:
+            per_image = [int(x) for x in num_splits[i]]
+            if sum(per_image) != n_tiles or any(x <= 0 for x in per_image):
+                raise RuntimeError(f"region_tile_index: num_splits[{i}] = {per_image} does not add up to {n_tiles} tiles")
+            if n > len(per_image):
+                raise RuntimeError(f"region_tile_index: sample {i} has {n} regions but {len(per_image)} images")
+            last, acc = [], 0
+            for x in per_image:
+                acc += x
+                last.append(off + acc - 1)
+            tiles += last[:n]
+        else:
+            tiles += [off + n_tiles - 1] * n
+        off += n_tiles
+    return tiles
+
+
+def gather_region_images(images, num_regions, num_splits=None):
+    """all_images of the region branch (modeling_visionllmv2.py:626-643): [n_all_regions, 3, h, w] -- one image per region.
+    ``images``: list of per-sample tile stacks ('anyres' / mmic) or one [B, 3, h, w] tensor ('pad').  Pixels feed the region
+    encoder's conv stem (torch), so this is a plain index_select."""
+    if isinstance(images, (list, tuple)):
+        tiles = region_tile_index([len(x) for x in images], num_regions, num_splits)
+        cat = torch.cat(list(images), dim=0)
+    else:
+        tiles = region_tile_index(None, num_regions, n_images=images.shape[0])
+        cat = images
+    return cat.index_select(0, torch.as_tensor(tiles, dtype=torch.long, device=cat.device))
+
+
+def gather_region_image_features(hidden_states, split_sizes, num_regions, levels=(-3, -2, -1), num_splits=None):
+    """Region branch, feature selection (modeling_visionllmv2.py:644-676): for every region the features of ITS image's
+    global tile without CLS, at the last three encoder levels (see region_tile_index for the three input conventions;
+    ``split_sizes`` None = 'pad').  hidden_states: indexable of [n_tiles, 1 + T, C] bf16; -> list of [n_all_regions, T, C]
+    (one native row gather per level)."""
     outs = []
     dev = hidden_states[levels[0]].device
-    last_tile = torch.tensor([sum(split_sizes[: i + 1]) - 1 for i in range(len(split_sizes))], device=dev, dtype=torch.int64)
-    tile_of_region = last_tile.repeat_interleave(torch.as_tensor(num_regions, device=dev))
+    n_tiles = hidden_states[levels[0]].shape[0]
+    tiles = region_tile_index(split_sizes, num_regions, num_splits, n_images=n_tiles)
+    if split_sizes is not None and sum(int(x) for x in split_sizes) != n_tiles:
+        raise RuntimeError(f"gather_region_image_features: split_sizes add up to {sum(split_sizes)}, the encoder saw {n_tiles} tiles")
+    tile_of_region = torch.tensor(tiles, device=dev, dtype=torch.int64)
     for lv in levels:
-        hs = hidden_states[lv].contiguous()
+        hs = hidden_states[lv]
+        _no_grad_path("gather_region_image_features", hs)
+        hs = hs.contiguous()
         n, S1, C = hs.shape
         T = S1 - 1
         src = (tile_of_region[:, None] * S1 + 1 + torch.arange(T, device=dev)[None, :]).reshape(-1)
-        out = torch.empty((tile_of_region.numel(), T, C), dtype=hs.dtype, device=dev)
+        out = torch.empty((tile_of_region.numel(), T, C), dtype=hs.dtype, device=dev)   # every row is written: src covers all of it
         _copy_rows(hs.view(n * S1, C), src, out.view(-1, C), None, src.numel())
         outs.append(out)
     return outs
@@ -139,6 +212,7 @@ def gather_region_image_features(hidden_states, split_sizes, num_regions, levels
 def splice_region_tokens(inputs_embeds, input_ids, reg_token_id, region_features):
     """<region> slots (modeling_visionllmv2.py:688-695): inputs_embeds[input_ids == reg_token_id] = region_features, in place."""
     B, L, C = inputs_embeds.shape
+    _no_grad_path("splice_region_tokens", inputs_embeds, region_features)
     dst = torch.nonzero((input_ids == reg_token_id).reshape(-1), as_tuple=False).reshape(-1)
     feats = region_features.to(inputs_embeds.dtype).reshape(-1, C).contiguous()
     if dst.numel() != feats.shape[0]:
