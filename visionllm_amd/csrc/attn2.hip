@@ -25,6 +25,7 @@
 // VAR bit0: s_setprio 1 around the MFMA clusters; bit1: the exponentials of key block 1 are placed between the P V MFMAs
 // of key block 0 (in-wave overlap); bit2: row sums by fp32 adds instead of v_dot2c_f32_bf16.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.hpp"
 #include "kernels.hpp"
 #include "attn_common.hpp"
@@ -113,20 +114,15 @@ __device__ __forceinline__ void stage2(__amdgpu_buffer_rsrc_t rs, uint32_t tile_
                                                  16, (int)vo[s], (int)tile_off, 0, 0);
 }
 
-// Work items.  An item = one block of QBLK query rows of one (batch, head).  XCD x owns the (batch, head) pairs
-// bh = x, x + 8, ... (all query blocks of a pair on one XCD: its K/V stay in that L2) and its items are numbered
-// i = (bh / 8) * nqt + qt; block k of the XCD (k = blockIdx / 8, K = gridDim / 8 blocks per XCD) runs items k, k + K, ...
-// With K >= the item count every block runs one item (the launch of rounds 1-2); the default launch is PERSISTENT: K = the
-// blocks the XCD's CUs hold, and the K/V tiles of a block's items form ONE stream through the LDS ring -- the first tile of
-// the next item is requested during the last tile of the current one, its Q rows right after the last QK^T cluster, and the
-// output rows of an item are stored behind the first barrier of the next item.  What that removes (ablation builds, round 3,
-// profiles/r03_attn2_ablation.txt): a kernel of nothing but prologue + barriers + epilogue took 30 of 80 us (d = 64) and
-// 46 of 133 us (d = 128) -- per-block launch, Q / first-tile latency and store drain that only other blocks could hide.
-struct AttnItem {
-    int b, head, qt;      // wave-uniform
-    bool valid;
-};
-
+// Work.  XCD x owns the (batch, head) pairs bh = x, x + 8, ... (all query rows of a pair on one XCD: its K/V stay in that
+// L2).  A block processes `a.nq` CONSECUTIVE query tiles (QBLK rows each) of ONE pair, one after the other, and the K/V
+// tiles of these passes form ONE stream through the 2-slot LDS ring: the first tile of the next pass is requested during
+// the last tile of the current one (same descriptors, tile offset wraps to 0).  With nq = all query tiles (the launch
+// default for batches that fill the chip) a (batch, head) pair is ONE block: one dispatch, one cold start, and the
+// nearly empty last query tile (S = 577 / 1025: 65 / 1 live rows) is the tail of a long block instead of a block of its
+// own that occupies a CU slot for a full K/V sweep.  What that buys (profiles/r03_attn2_skeleton.txt: 3200 blocks of 2 / 4 /
+// 10 / 19 KV tiles): a block costs 2.4 us + 1.37 us per tile at d = 64 and 5.8 us + 1.62 us per tile at d = 128 -- 15 - 17 %
+// of a launch was per-block dispatch, Q / first-tile latency and store drain.
 template <int D, int VAR>
 __global__ __launch_bounds__(ATT_THREADS, D == 64 ? 3 : 2) void attn_fwd2_kernel(const AttnArgs a)
 {
@@ -136,55 +132,35 @@ __global__ __launch_bounds__(ATT_THREADS, D == 64 ? 3 : 2) void attn_fwd2_kernel
     constexpr int NV = 4 * DB;            // V transpose-reads per 32-key block (2 halves of 16 keys x DB x {lo, hi})
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
     constexpr float THR = 6.0f;           // deferred rescale (exp2 domain): P stays below 2^6
-    constexpr bool QLATE = D == 128;
+    constexpr bool QEARLY = D == 64;      // the next pass's Q rows are requested right after the last QK^T (registers allow it)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 slots][K | V]
 
     if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();   // fragment reads address LDS by byte offset: no static LDS here
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3, kstride = gridDim.x >> 3;
-    const int BH = a.B * a.H;
-    const int n_items = xcd < BH ? ((BH - xcd + 7) >> 3) * a.nqt : 0;   // items of this XCD
-    auto item_of = [&](int i) {
-        AttnItem it;
-        it.valid = i < n_items;
-        const int ii = it.valid ? i : 0;
-        const int bh = (ii / a.nqt) * 8 + xcd;
-        it.qt = ii % a.nqt;
-        it.b = bh / a.H;
-        it.head = bh - it.b * a.H;
-        return it;
-    };
-    if (kblk >= n_items) return;
+    // ---- block -> (b, head, first query tile) ----
+    const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+    const int nchunk = (a.nqt + a.nq - 1) / a.nq;          // blocks per (b, head)
+    const int bh = (sidx / nchunk) * 8 + xcd;
+    if (bh >= a.B * a.H) return;
+    const int qt0 = (sidx % nchunk) * a.nq;
+    const int qt1 = min(a.nqt, qt0 + a.nq);
+    const int b = bh / a.H, head = bh % a.H;
 
+    const uint16_t *qb = a.q + (long)b * a.q_bs + (long)head * a.q_hs;
+    const uint16_t *kb_ = a.k + (long)b * a.k_bs + (long)head * a.k_hs;
+    const uint16_t *vb_ = a.v + (long)b * a.v_bs + (long)head * a.v_hs;
+    // descriptors that end with the last element of key S-1: rows of a ragged last tile beyond it read as zero
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)kb_, 0, ((a.S - 1) * a.k_ts + D) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)vb_, 0, ((a.S - 1) * a.v_ts + D) * 2, 0x00020000);
     uint32_t kvo[Stage2<D>::NI], vvo[Stage2<D>::NI];
     stage2_offsets<D, false>(a.k_ts, wave, lane, kvo);
     stage2_offsets<D, true>(a.v_ts, wave, lane, vvo);
     const uint32_t k_step = (uint32_t)(KVBLK * a.k_ts * 2), v_step = (uint32_t)(KVBLK * a.v_ts * 2);   // bytes per tile
-    const int k_bytes = ((a.S - 1) * a.k_ts + D) * 2, v_bytes = ((a.S - 1) * a.v_ts + D) * 2;
-    // descriptors that end with the last element of key S-1: rows of a ragged last tile beyond it read as zero
-    auto k_desc = [&](const AttnItem &it) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.k + (long)it.b * a.k_bs + (long)it.head * a.k_hs), 0, k_bytes, 0x00020000);
-    };
-    auto v_desc = [&](const AttnItem &it) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + (long)it.b * a.v_bs + (long)it.head * a.v_hs), 0, v_bytes, 0x00020000);
-    };
+
     const int nkt = (a.S + KVBLK - 1) / KVBLK;
     const bool short_tail = a.S - (nkt - 1) * KVBLK <= 32;
-
-    // ---- Q fragments (B operand): lane (q = l31, hh) holds Q[q][16*ks + 8*hh .. +7] ----
-    bf16x8_t qf[KS];
-    auto load_q = [&](const AttnItem &it) {
-        const int q_row = it.qt * QBLK + wave * 32 + l31;
-        const int q_ld = q_row < a.S ? q_row : a.S - 1;
-        const uint16_t *qb = a.q + (long)it.b * a.q_bs + (long)it.head * a.q_hs + (long)q_ld * a.q_ts + hh * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t *>(qb + ks * 16);
-    };
-
-    f32x16_t o[DB];
-    float m_run = -1.0e30f, l_run = 0.f;
     const float c2 = a.scale_log2e;
 
     // Per-lane LDS offsets (the addresses of attn_fwd_kernel).  The swizzles are XORs of 16-byte chunk numbers, so the
@@ -198,190 +174,250 @@ __global__ __launch_bounds__(ATT_THREADS, D == 64 ? 3 : 2) void attn_fwd2_kernel
         vofs0 = (uint32_t)(krow * (D * 2) + ((c ^ swz_v<D>(krow)) << 4) + (((lane & 15) & 1) << 3)) + (uint32_t)TILE;
     }
 
-    // exponentials + bf16 packing + row sum of ONE 32-key block
-    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-    auto exp_block = [&](const f32x16_t &s, uint32_t (&pk)[8], float &sum0, float &sum1) {
-        const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
+    // ---- Q fragments (B operand): lane (q = l31, hh) holds Q[q][16*ks + 8*hh .. +7] ----
+    bf16x8_t qf[KS];
+    auto load_q = [&](int qt) {
+        const int q_row = qt * QBLK + wave * 32 + l31;
+        const int q_ld = q_row < a.S ? q_row : a.S - 1;
+        const uint16_t *qp = qb + (long)q_ld * a.q_ts + hh * 8;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const float p0 = (ATTN2_ABL & 1) ? fmaf(s[r], c2, -m_run) : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m_run));
-            const float p1 = (ATTN2_ABL & 1) ? fmaf(s[r + 1], c2, -m_run) : __builtin_amdgcn_exp2f(fmaf(s[r + 1], c2, -m_run));
-            const uint32_t w = pack_bf16x2(p0, p1);
-            pk[r >> 1] = w;
-            float &acc = ((r >> 1) & 1) ? sum1 : sum0;
-            // sums of the bf16-ROUNDED probabilities (the ones the P V product uses): O / l normalises what was accumulated
-            if constexpr (ADDSUM) acc += bf16lo_to_f32(w) + bf16hi_to_f32(w);
-            else acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w), ones, acc, false);
-        }
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t *>(qp + ks * 16);
     };
-    // O^T += V^T P^T for one 32-key block: 2 * DB MFMAs on fragments already in registers.
-    // k-slots of step u: regs 8u..8u+7 <-> keys 16u + 4hh + {0..3, 8..11} of the block
-    auto pv_block = [&](const uint32_t (&pk)[8], const s16x4_t (&hv)[NV]) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 pw = {pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]};
-            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const s16x4_t v_lo = hv[(u * DB + d) * 2], v_hi = hv[(u * DB + d) * 2 + 1];
-                const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
-                if constexpr ((ATTN2_ABL & 8) != 0) { o[d][0] += __builtin_bit_cast(float, (int)vf[0] + (int)pf[0]); continue; }
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-            }
+    // the tile after tile t of a pass: the next one, or the first of the next pass (block-uniform)
+    auto stage_next = [&](int t, bool more_passes, uint32_t slot) {
+        if (ATTN2_ABL & 16) return;
+        const int tn = t + 1 < nkt ? t + 1 : 0;
+        if (t + 1 < nkt || more_passes) {
+            char *nx = smem + (2 * TILE - slot);
+            stage2<D>(krs, (uint32_t)tn * k_step, nx, wave, kvo);
+            stage2<D>(vrs, (uint32_t)tn * v_step, nx + TILE, wave, vvo);
         }
     };
 
-    // The arithmetic of one KV tile (this wave's 32 query rows against the tile in ring slot `slot`).  NKB: live 32-key
-    // blocks (1: the last tile holds <= 32 live keys -- S = 577 / 1025: the single CLS-offset key).  `prefetch_q`: after
-    // the QK^T cluster (the last one of the item) the Q registers are dead and are re-loaded for the next item.
-    auto tile_math = [&](int k0, uint32_t slot, auto nkb_, bool prefetch_q, const AttnItem &nxt) {
-        constexpr int NKB = decltype(nkb_)::value;
-        uint32_t kbase = kofs0 + slot, vbase = vofs0 + slot;
-        asm volatile("" : "+v"(kbase), "+v"(vbase));   // per tile: hoisted, these become KS + DB registers per slot
-        // ---- K fragments of the whole tile -> registers, in the order the MFMAs consume them ----
-        // The two key blocks' accumulators alternate (no MFMA waits for the one before it); the first half of the k-steps
-        // is released by a counted wait while the second half is still in flight.
-        bf16x8_t kfa[KS], kfb[KS];   // kfa: k-steps 0 .. KS/2-1 of {block 0, block 1}; kfb: the rest
-        static_for<0, KS>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            if constexpr (NKB == 2) kfa[i] = lds_b128<(i % 2) * 32 * (D * 2)>(kbase ^ (uint32_t)((i / 2) << 5));
-            else kfa[i] = lds_b128<0>(kbase ^ (uint32_t)(i << 5));   // one live key block: all KS k-steps of block 0
-        });
-        if constexpr (NKB == 2) {
+    stage2<D>(krs, 0u, smem, wave, kvo);
+    stage2<D>(vrs, 0u, smem + TILE, wave, vvo);
+    if (qt0 * QBLK + wave * 32 < a.S) load_q(qt0);
+    uint32_t slot = 0;               // ring slot of the tile being processed: 0 or 2 * TILE
+    // Blocks of equal work that start together run in LOCKSTEP on a CU: their QK^T / softmax / P V phases coincide and
+    // compete for the same pipe instead of filling each other's gaps (measured: all query tiles in one block, no stagger,
+    // 101 vs 80 us at d = 64).  The k-th block a CU receives in the first wave of dispatches (blockIdx / #CUs) starts
+    // a.stagger * k cycles late -- what the dispatcher's natural skew does for short blocks.
+    if (a.stagger > 0) {
+        const int k = blockIdx.x / a.n_cu;
+        for (int i = 0; i < k * a.stagger; i += 64 * 16) __builtin_amdgcn_s_sleep(16);
+    }
+
+    for (int qt = qt0; qt < qt1; ++qt) {
+        const bool more = qt + 1 < qt1;
+        const bool live_wave = qt * QBLK + wave * 32 < a.S;
+        if (!live_wave) {
+            // a wave whose 32 query rows are all padding (the last query tile of S = 577 / 1025) only stages its share of the
+            // K/V tiles and keeps the barrier count.  (Its own loop: carried through the loop below, the unused accumulators
+            // of such a wave cost every live wave a 64-register copy per tile at the join.)
+            for (int t = 0; t < nkt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(ATTN2_ABL & 64)) __syncthreads();
+                stage_next(t, more, slot);
+                slot = 2 * TILE - slot;
+            }
+            continue;
+        }
+        f32x16_t o[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m_run = -1.0e30f, l_run = 0.f;
+
+        // exponentials + bf16 packing + row sum of ONE 32-key block
+        typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+        auto exp_block = [&](const f32x16_t &s, uint32_t (&pk)[8], float &sum0, float &sum1) {
+            const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = (ATTN2_ABL & 1) ? fmaf(s[r], c2, -m_run) : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m_run));
+                const float p1 = (ATTN2_ABL & 1) ? fmaf(s[r + 1], c2, -m_run) : __builtin_amdgcn_exp2f(fmaf(s[r + 1], c2, -m_run));
+                const uint32_t w = pack_bf16x2(p0, p1);
+                pk[r >> 1] = w;
+                float &acc = ((r >> 1) & 1) ? sum1 : sum0;
+                // sums of the bf16-ROUNDED probabilities (the ones the P V product uses): O / l normalises what was accumulated
+                if constexpr (ADDSUM) acc += bf16lo_to_f32(w) + bf16hi_to_f32(w);
+                else acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w), ones, acc, false);
+            }
+        };
+        // O^T += V^T P^T for one 32-key block: 2 * DB MFMAs on fragments already in registers.
+        // k-slots of step u: regs 8u..8u+7 <-> keys 16u + 4hh + {0..3, 8..11} of the block
+        auto pv_block = [&](const uint32_t (&pk)[8], const s16x4_t (&hv)[NV]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 pw = {pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]};
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const s16x4_t v_lo = hv[(u * DB + d) * 2], v_hi = hv[(u * DB + d) * 2 + 1];
+                    const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
+                    if constexpr ((ATTN2_ABL & 8) != 0) { o[d][0] += __builtin_bit_cast(float, (int)vf[0] + (int)pf[0]); continue; }
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                }
+            }
+        };
+
+        // One KV tile.  NKB: live 32-key blocks (1: the last tile holds <= 32 live keys -- S = 577 / 1025: the single
+        // CLS-offset key).  Everything else about the tile is a run-time scalar.
+        auto tile_step = [&](int t, auto nkb_) {
+            constexpr int NKB = decltype(nkb_)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(ATTN2_ABL & 64)) __syncthreads();   // tile t landed for every wave; everyone is done reading the other slot
+            stage_next(t, more, slot);
+            const int k0 = t * KVBLK;
+            uint32_t kbase = kofs0 + slot, vbase = vofs0 + slot;
+            asm volatile("" : "+v"(kbase), "+v"(vbase));   // per tile: hoisted, these become KS + DB registers per slot
+            // ---- K fragments of the whole tile -> registers, in the order the MFMAs consume them ----
+            // The two key blocks' accumulators alternate (no MFMA waits for the one before it); the first half of the
+            // k-steps is released by a counted wait while the second half is still in flight.
+            bf16x8_t kfa[KS], kfb[KS];   // kfa: k-steps 0 .. KS/2-1 of {block 0, block 1}; kfb: the rest
             static_for<0, KS>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                kfb[i] = lds_b128<(i % 2) * 32 * (D * 2)>(kbase ^ (uint32_t)((KS / 2 + i / 2) << 5));
+                if constexpr (NKB == 2) kfa[i] = lds_b128<(i % 2) * 32 * (D * 2)>(kbase ^ (uint32_t)((i / 2) << 5));
+                else kfa[i] = lds_b128<0>(kbase ^ (uint32_t)(i << 5));   // one live key block: all KS k-steps of block 0
             });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- S^T = K Q^T: dense MFMA cluster ----
-        f32x16_t st0, st1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
-        wait_lgkm<NKB == 2 ? KS : 0>(kfa);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        if constexpr (NKB == 2) {
-#pragma unroll
-            for (int i = 0; i < KS; i += 2) {
-                if constexpr ((ATTN2_ABL & 4) != 0) { st0[i] += __builtin_bit_cast(float, (int)kfa[i][0]); st1[i] += __builtin_bit_cast(float, (int)kfa[i + 1][0]); continue; }
-                st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i], qf[i / 2], st0, 0, 0, 0);
-                st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i + 1], qf[i / 2], st1, 0, 0, 0);
+            if constexpr (NKB == 2) {
+                static_for<0, KS>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    kfb[i] = lds_b128<(i % 2) * 32 * (D * 2)>(kbase ^ (uint32_t)((KS / 2 + i / 2) << 5));
+                });
             }
-            pin(st0); pin(st1);
-            wait_lgkm<0>(kfb);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S^T = K Q^T: dense MFMA cluster ----
+            f32x16_t st0, st1;
 #pragma unroll
-            for (int i = 0; i < KS; i += 2) {
-                if constexpr ((ATTN2_ABL & 4) != 0) { st0[i + 8] += __builtin_bit_cast(float, (int)kfb[i][0]); st1[i + 8] += __builtin_bit_cast(float, (int)kfb[i + 1][0]); continue; }
-                st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[i], qf[KS / 2 + i / 2], st0, 0, 0, 0);
-                st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[i + 1], qf[KS / 2 + i / 2], st1, 0, 0, 0);
-            }
-            pin(st0); pin(st1);
-        } else {
+            for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
+            wait_lgkm<NKB == 2 ? KS : 0>(kfa);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            if constexpr (NKB == 2) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[ks], qf[ks], st0, 0, 0, 0);
-            pin(st0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // (block-uniform) the item's last QK^T is done and the Q registers are dead: the next item's Q rows are requested
-        // here (d = 64) and land under the rest of the tile; at d = 128 there are no 32 free registers until the V
-        // fragments are consumed, so they are requested at the end of the tile (and waited for at the next barrier)
-        if (!QLATE && prefetch_q) {
-            if (nxt.valid && nxt.qt * QBLK + wave * 32 < a.S) load_q(nxt);
-        }
-        // ---- V fragments of key block 0 -> registers (in flight under the softmax) ----
-        // hv[(u * DB + d) * 2 + {0, 1}]: keys 16u + 4hh + i16/4 (+ 8) of the key block, chunk of output block d
-        s16x4_t hv0[NV], hv1[NV];
-        static_for<0, 2 * DB>([&](auto i_) {
-            constexpr int i = decltype(i_)::value, u = i / DB, d = i % DB;
-            hv0[i * 2] = lds_tr_b64<(16 * u) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
-            hv0[i * 2 + 1] = lds_tr_b64<(16 * u + 8) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- online softmax (exp2 domain, deferred rescale) ----
-        float ps0 = 0.f, ps1 = 0.f;
-        uint32_t pk0[8], pk1[8];
-        if constexpr ((ATTN2_ABL & 2) != 0) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) { pk0[r >> 1] = pack_bf16x2(st0[r], st0[r + 1]); pk1[r >> 1] = pack_bf16x2(st1[r], st1[r + 1]); }
-        } else {
-            if (k0 + KVBLK > a.S) {   // block-uniform: the ragged last tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    st0[r] = key < a.S ? st0[r] : -1.0e30f;
-                    if (NKB == 2) st1[r] = key + 32 < a.S ? st1[r] : -1.0e30f;
+                for (int i = 0; i < KS; i += 2) {
+                    if constexpr ((ATTN2_ABL & 4) != 0) { st0[i] += __builtin_bit_cast(float, (int)kfa[i][0]); st1[i] += __builtin_bit_cast(float, (int)kfa[i + 1][0]); continue; }
+                    st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i], qf[i / 2], st0, 0, 0, 0);
+                    st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i + 1], qf[i / 2], st1, 0, 0, 0);
                 }
+                pin(st0); pin(st1);
+                wait_lgkm<0>(kfb);
+#pragma unroll
+                for (int i = 0; i < KS; i += 2) {
+                    if constexpr ((ATTN2_ABL & 4) != 0) { st0[i + 8] += __builtin_bit_cast(float, (int)kfb[i][0]); st1[i + 8] += __builtin_bit_cast(float, (int)kfb[i + 1][0]); continue; }
+                    st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[i], qf[KS / 2 + i / 2], st0, 0, 0, 0);
+                    st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[i + 1], qf[KS / 2 + i / 2], st1, 0, 0, 0);
+                }
+                pin(st0); pin(st1);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[ks], qf[ks], st0, 0, 0, 0);
+                pin(st0);
             }
-            float mx = -1.0e30f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st0[r]);
-            if constexpr (NKB == 2) {   // (its own chain: the two blocks' maxima are independent until here)
-                float mx1 = -1.0e30f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx1 = fmaxf(mx1, st1[r]);
-                mx = fmaxf(mx, mx1);
-            }
-            mx = halves_max(mx) * c2;                    // c2 > 0: max commutes with the scaling
-            if (!__all(mx - m_run <= THR)) {             // wave-uniform; both halves of a query agree on mx
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            exp_block(st0, pk0, ps0, ps1);
-            if constexpr (NKB == 2 && !SPLIT) exp_block(st1, pk1, ps0, ps1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- O^T += V^T P^T ----  (key block 1's V fragments are requested here and land under key block 0's MFMAs)
-        wait_lgkm<0>(hv0);
-        if constexpr (NKB == 2) {
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // (block-uniform) the pass's last QK^T is done and the Q registers are dead: d = 64 requests the next pass's Q rows
+            // here, in flight under the rest of the tile
+            if (QEARLY && t == nkt - 1 && more && (qt + 1) * QBLK + wave * 32 < a.S) load_q(qt + 1);
+            // ---- V fragments of key block 0 -> registers (in flight under the softmax) ----
+            // hv[(u * DB + d) * 2 + {0, 1}]: keys 16u + 4hh + i16/4 (+ 8) of the key block, chunk of output block d
+            s16x4_t hv0[NV], hv1[NV];
             static_for<0, 2 * DB>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, u = i / DB, d = i % DB;
-                hv1[i * 2] = lds_tr_b64<(32 + 16 * u) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
-                hv1[i * 2 + 1] = lds_tr_b64<(32 + 16 * u + 8) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
+                hv0[i * 2] = lds_tr_b64<(16 * u) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
+                hv0[i * 2 + 1] = lds_tr_b64<(16 * u + 8) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
             });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        pv_block(pk0, hv0);
-        if constexpr (NKB == 2) {
-            if constexpr (SPLIT && !(ATTN2_ABL & 2)) {
-                // key block 0's MFMAs and key block 1's exponentials in ONE scheduling region: a few VALU per MFMA gap
-                exp_block(st1, pk1, ps0, ps1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- online softmax (exp2 domain, deferred rescale) ----
+            float ps0 = 0.f, ps1 = 0.f;
+            uint32_t pk0[8], pk1[8];
+            if constexpr ((ATTN2_ABL & 2) != 0) {
 #pragma unroll
-                for (int i = 0; i < 2 * DB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 56 / (2 * DB), 0);        // its share of the ~56 VALU / TRANS
+                for (int r = 0; r < 16; r += 2) { pk0[r >> 1] = pack_bf16x2(st0[r], st0[r + 1]); pk1[r >> 1] = pack_bf16x2(st1[r], st1[r + 1]); }
+            } else {
+                if (k0 + KVBLK > a.S) {   // block-uniform: the ragged last tile
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        st0[r] = key < a.S ? st0[r] : -1.0e30f;
+                        if (NKB == 2) st1[r] = key + 32 < a.S ? st1[r] : -1.0e30f;
+                    }
                 }
+                float mx = -1.0e30f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st0[r]);
+                if constexpr (NKB == 2) {   // (its own chain: the two blocks' maxima are independent until here)
+                    float mx1 = -1.0e30f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx1 = fmaxf(mx1, st1[r]);
+                    mx = fmaxf(mx, mx1);
+                }
+                mx = halves_max(mx) * c2;                    // c2 > 0: max commutes with the scaling
+                if (!__all(mx - m_run <= THR)) {             // wave-uniform; both halves of a query agree on mx
+                    const float m_new = fmaxf(m_run, mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                }
+                exp_block(st0, pk0, ps0, ps1);
+                if constexpr (NKB == 2 && !SPLIT) exp_block(st1, pk1, ps0, ps1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- O^T += V^T P^T ----  (key block 1's V fragments are requested here and land under key block 0's MFMAs)
+            wait_lgkm<0>(hv0);
+            if constexpr (NKB == 2) {
+                static_for<0, 2 * DB>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value, u = i / DB, d = i % DB;
+                    hv1[i * 2] = lds_tr_b64<(32 + 16 * u) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
+                    hv1[i * 2 + 1] = lds_tr_b64<(32 + 16 * u + 8) * (D * 2)>(vbase ^ (uint32_t)(d << 6));
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            pv_block(pk0, hv0);
+            if constexpr (NKB == 2) {
+                if constexpr (SPLIT && !(ATTN2_ABL & 2)) {
+                    // key block 0's MFMAs and key block 1's exponentials in ONE scheduling region: a few VALU per MFMA gap
+                    exp_block(st1, pk1, ps0, ps1);
+#pragma unroll
+                    for (int i = 0; i < 2 * DB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 56 / (2 * DB), 0);        // its share of the ~56 VALU / TRANS
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < DB; ++d) pin(o[d]);
+                if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);
+                wait_lgkm<0>(hv1);
+                pv_block(pk1, hv1);
             }
 #pragma unroll
             for (int d = 0; d < DB; ++d) pin(o[d]);
-            if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);
-            wait_lgkm<0>(hv1);
-            pv_block(pk1, hv1);
-        }
-#pragma unroll
-        for (int d = 0; d < DB; ++d) pin(o[d]);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        l_run += ps0 + ps1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (QLATE && prefetch_q) {
-            if (nxt.valid && nxt.qt * QBLK + wave * 32 < a.S) load_q(nxt);
-        }
-    };
-    // O / l -> bf16 rows; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31
-    auto store_out = [&](const AttnItem &it) {
-        const int q_row = it.qt * QBLK + wave * 32 + l31;
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            l_run += ps0 + ps1;
+            __builtin_amdgcn_sched_barrier(0);
+            slot = 2 * TILE - slot;
+        };
+        constexpr std::integral_constant<int, 1> ONE_BLOCK{};
+        constexpr std::integral_constant<int, 2> TWO_BLOCKS{};
+        for (int t = 0; t < nkt - 1; ++t) tile_step(t, TWO_BLOCKS);
+        if (short_tail) tile_step(nkt - 1, ONE_BLOCK); else tile_step(nkt - 1, TWO_BLOCKS);
+
+        // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
+        // (d = 128: the next pass's Q rows are requested first -- every fragment register is free now -- and land under
+        //  the normalisation and the stores)
+        if (!QEARLY && more && (qt + 1) * QBLK + wave * 32 < a.S) load_q(qt + 1);
+        const int q_row = qt * QBLK + wave * 32 + l31;
         const float l_tot = halves_sum(l_run);
         const float inv = 1.0f / l_tot;
         if (q_row < a.S) {
-            uint16_t *orow = a.out + (((long)it.b * a.S + q_row) * a.H + it.head) * D;
+            uint16_t *orow = a.out + (((long)b * a.S + q_row) * a.H + head) * D;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -392,62 +428,7 @@ __global__ __launch_bounds__(ATT_THREADS, D == 64 ? 3 : 2) void attn_fwd2_kernel
                     *reinterpret_cast<uint2_t *>(orow + d * 32 + 8 * rq + 4 * hh) = w;
                 }
         }
-    };
-    constexpr std::integral_constant<int, 1> ONE_BLOCK{};
-    constexpr std::integral_constant<int, 2> TWO_BLOCKS{};
-
-    // ---- the tile stream ----
-    int inext = kblk;
-    AttnItem cur = item_of(inext), prev = cur, nxt;
-    inext += kstride;
-    nxt = item_of(inext);
-    bool have_prev = false;          // prev's output rows are still in o / l_run (stored behind the next barrier)
-    bool live = cur.qt * QBLK + wave * 32 < a.S, prev_live = false;
-    __amdgpu_buffer_rsrc_t krs = k_desc(cur), vrs = v_desc(cur);
-    stage2<D>(krs, 0u, smem, wave, kvo);
-    stage2<D>(vrs, 0u, smem + TILE, wave, vvo);
-    if (live) load_q(cur);
-    uint32_t slot = 0;               // ring slot of the tile being processed: 0 or 2 * TILE
-    for (int t = 0;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(ATTN2_ABL & 64)) __syncthreads();   // this tile landed for every wave; everyone is done reading the other slot
-        // the tile after this one: the next of this item, or the first of the next item
-        const bool last = t == nkt - 1;
-        if (!(ATTN2_ABL & 16) || t == 0) {
-            char *nx = smem + (2 * TILE - slot);
-            if (!last) {
-                stage2<D>(krs, (uint32_t)(t + 1) * k_step, nx, wave, kvo);
-                stage2<D>(vrs, (uint32_t)(t + 1) * v_step, nx + TILE, wave, vvo);
-            } else if (nxt.valid) {
-                krs = k_desc(nxt); vrs = v_desc(nxt);
-                stage2<D>(krs, 0u, nx, wave, kvo);
-                stage2<D>(vrs, 0u, nx + TILE, wave, vvo);
-            }
-        }
-        if (t == 0) {   // (block-uniform) a new item: the previous one's rows leave now, behind the barrier
-            if (have_prev && prev_live) store_out(prev);
-#pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-            m_run = -1.0e30f; l_run = 0.f;
-        }
-        if (live) {
-            if (last && short_tail) tile_math(t * KVBLK, slot, ONE_BLOCK, true, nxt);
-            else tile_math(t * KVBLK, slot, TWO_BLOCKS, last, nxt);
-        }
-        slot = 2 * TILE - slot;
-        if (!last) { ++t; continue; }
-        // item done
-        prev = cur; prev_live = live; have_prev = true;
-        if (!nxt.valid) break;
-        cur = nxt;
-        live = cur.qt * QBLK + wave * 32 < a.S;
-        inext += kstride;
-        nxt = item_of(inext);
-        t = 0;
     }
-    if (prev_live) store_out(prev);
 }
 
 }  // namespace
@@ -458,18 +439,25 @@ int attn_fwd2_launch(AttnArgs a, int D, int var2, hipStream_t st)
     VLLM_REQUIRE(((long)a.S * a.k_ts + D) * 2 < (1l << 31) && ((long)a.S * a.v_ts + D) * 2 < (1l << 31),
                  "attn: a (batch, head) K/V slab must stay below 2 GiB (S=%d, token stride %d)", a.S, a.k_ts);
     const long groups = ((long)a.B * a.H + 7) / 8;
-    long nblk = groups * 8 * a.nqt;                       // one block per item ...
-    if (!(var2 & 8)) {                                    // ... or (default) persistent: the blocks the chip holds
-        static int cus = 0;
-        if (cus == 0) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                      ? prop.multiProcessorCount : 256;
-        }
-        const long cap = (long)(cus / 8) * 8 * (D == 64 ? 3 : 2);
-        if (nblk > cap) nblk = cap;
+    // Query tiles per block: ONE (default).  Letting a block walk ALL query tiles of its (batch, head) pair (var2 bit 3;
+    // one dispatch and one cold start per pair, no nearly empty tail block) measured SLOWER on MI355X: 101 vs 80 us at
+    // 40 x 16 x S577 x d64 and 823 vs 669 us at 40 x 25 x S1025 x d128 (profiles/r03_attn2_nq_and_stagger.txt) -- the pair's
+    // K/V is then re-read 5 / 9 times over a long period by one CU instead of being shared, within a few microseconds, by
+    // the 5 / 9 blocks of the pair running side by side on the XCD: the concurrently live pairs (64-96 per XCD x 148-524 KB)
+    // no longer fit the 4 MiB L2.  A start skew between the blocks of a CU (a.stagger) changed nothing (102-104 us).
+    static int cus = 0;
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
     }
+    a.nq = (var2 & 8) ? a.nqt : 1;
+    // stagger (cycles between the blocks of a CU): a third / half of a tile's time; VLLM_ATTN_STAGGER overrides (0 = off)
+    static const int stagger_env = [] { const char *e = getenv("VLLM_ATTN_STAGGER"); return e ? atoi(e) : -1; }();
+    a.n_cu = cus;
+    a.stagger = a.nq > 1 ? (stagger_env >= 0 ? stagger_env : (D == 64 ? 1100 : 2000)) : 0;
+    const long nblk = groups * 8 * ((a.nqt + a.nq - 1) / a.nq);
     const dim3 grid((unsigned)nblk), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
 #define LA2(DD, V) VLLM_LAUNCH((attn_fwd2_kernel<DD, V>), grid, block, lds, st, a)

@@ -82,6 +82,8 @@ struct AttnArgs {
     int q_hs, k_hs, v_hs;       // head strides
     int B, S, H;
     int nqt;                    // query tiles per (b, h) (filled by the launcher)
+    int nq = 1;                 // schedule 2: consecutive query tiles one block processes (filled by the launcher)
+    int stagger = 0, n_cu = 256;   // schedule 2: start skew between the blocks of a CU [cycles], CUs of the device (launcher)
     int row0;                   // first query row of this launch (filled by the launcher)
     int no_trim;                // 1: process padding keys / padding query waves like live ones (A/B switch; launcher)
     float scale_log2e;

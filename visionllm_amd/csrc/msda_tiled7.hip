@@ -24,6 +24,13 @@
 #include "msda_sample.hpp"
 #include "msda_tiled6_helpers.hpp"
 
+// Timing-only ablation builds (tools/msda7_ablate.sh): -DT7_ABL=<mask> removes one cost at a time; results are wrong by
+// construction.  1: no multiply-adds in the gather, 2: no LDS reads in the gather, 4: no window DMA, 8: no output stores,
+// 16: no gather at all, 64: no per-item barrier.
+#ifndef T7_ABL
+#define T7_ABL 0
+#endif
+
 namespace vllm {
 
 namespace {
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         T7_TICK(2)   // box reduction
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the current item's windows has landed
         T7_TICK(3)   // wait for the own DMA
-        __syncthreads();   // (X) boxes of next complete; windows of cur landed; everyone is done gathering the item before cur
+        if (!(T7_ABL & 64)) __syncthreads();   // (X) boxes of next complete; windows of cur landed; everyone is done gathering the item before cur
         T7_TICK(4)   // barrier X
         const int4 bxn = *reinterpret_cast<const int4 *>(boxp + k * 4);   // lane l < 4: the box of level l
         // ---- S3: window placement (block-uniform).  The arena is shared by TWO items: one grows from the bottom, the next
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         T7_TICK(6)   // decode + prefetch issue
         // ---- cur's late level: its DMA goes out first, in one burst; it lands while the other levels are gathered ----
         const float *vbc = value + ((size_t)cb * S * M + cm) * D;
-        if (late_c >= 0 && late_c_placed) {
+        if (late_c >= 0 && late_c_placed && !(T7_ABL & 4)) {
             const int lay_l = __builtin_amdgcn_readlane(layc, late_c);
             const int y0 = __builtin_amdgcn_readlane(bxc.x, late_c), ny1 = __builtin_amdgcn_readlane(bxc.y, late_c);
             const int x0 = __builtin_amdgcn_readlane(bxc.z, late_c), nx1 = __builtin_amdgcn_readlane(bxc.w, late_c);
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
                 ddst = smem + (T6_ZPX + (lay_l & 0xffff)) * 128;
             }
             if (dl >= L) return;
+            if (T7_ABL & 4) { di0 += QPP; return; }
             const int pix = di0 + lpx;
             const int wy = (int)(((unsigned)pix * dmagic) >> 20), wx = pix - wy * dww;
             const int gy = dy0 + wy, gx = dx0 + wx;
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         const int b0 = qbi<LQ>(oc[I_]) + cA0, b1 = b0 ^ 64;                                                       \
         const int b0p = b0 + pitch, b1p = b1 + pitch;                                                            \
         float4_t a1, a2, a3, a4, c1, c2, c3, c4;                                                                 \
+        if (T7_ABL & 2) asm volatile("; no reads" : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4) : "v"(b0), "v"(b0p), "v"(b1), "v"(b1p)); else \
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:128\n\t"                                 \
                      "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:128\n\t"                                 \
                      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:128\n\t"                               \
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
                      : "v"(b0), "v"(b0p), "v"(b1), "v"(b1p)                                                      \
                      : "memory");                                                                                \
         const float e1 = qbf<LQ>(w1c[I_]), e2 = qbf<LQ>(w2c[I_]), e3 = qbf<LQ>(w3c[I_]), e4 = qbf<LQ>(w4c[I_]);  \
+        if (T7_ABL & 1) { acc[0] += a1[0] + a2[1] + a3[2] + a4[3] + e1; acc[4] += c1[0] + c2[1] + c3[2] + c4[3] + e2 + e3 + e4; } else \
         _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                       \
             float2_t t = {acc[c], acc[c + 1]};                                                                   \
             t = t6_fma2(e1, (float2_t){a1[c], a1[c + 1]}, t); t = t6_fma2(e2, (float2_t){a2[c], a2[c + 1]}, t);  \
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         T7_HOT_POINT(3, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
         dma_round();                                                                                             \
     }
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < ((T7_ABL & 16) ? 0 : 2); ++pass) {
                 const int want = pass ? 5 : 1;   // hot levels; then the late one, behind its DMA + a barrier
                 if (pass) {
                     if (!(late_c >= 0 && late_c_placed)) break;      // (block-uniform)
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         while (dl < L) dma_round();
         T7_TICK(9)   // remaining DMA issue
         if (cv) {
-            if (qokc) {
+            if (qokc && !(T7_ABL & 8)) {
                 if (out16) {   // the caller (the fused layer) wants the bf16 operand of output_proj
                     uint16_t *op = out16 + (size_t)prc * D;
                     uint2_t o1, o2;
@@ -484,5 +494,15 @@ int msda7_debug_counters(long *out, int n)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t7_prof), z, sizeof(z));
     return n < 16 ? n : 16;
 }
+
+#ifdef T7_ABL_ENTRY
+// test entry of the ablation builds (tools/msda7_ablate.py)
+extern "C" int t7_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B,
+                          int S, int M, int L, int Lq, float *out, void *stream)
+{
+    return msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, (hipStream_t)stream, nullptr, 1);
+}
+void set_error(const char *, ...) {}
+#endif
 
 }  // namespace vllm
