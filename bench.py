@@ -240,9 +240,9 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
     if "qk_norm" in in_step:
         ab = 2.0 * 2 * M * C * 2
         us, n = in_step["qk_norm"]
-        out["qk_norm"] = dict(kernel=f"norm_bf16_kernel x 2 (q and k RMSNorm over [{M}, {C}] slabs of qkv)", bound="hbm",
+        out["qk_norm"] = dict(kernel=f"norm_bf16_kernel (q and k RMSNorm, one launch over the [{M}, 2 x {C}] slab of qkv)", bound="hbm",
                               achieved=ab / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              traffic=None, us_per_launch=us, timing="in-step, both launches together", launches_per_step=n,
+                              traffic=None, us_per_launch=us, timing="in-step (event to event inside step())", launches_per_step=n,
                               algorithmic_bytes=ab)
     # optional: HBM traffic per launch from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -71,8 +71,10 @@ inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint1
     return gemm_bf16_launch(epi, a, st);
 }
 
+// G > 1: G column groups of C elements per memory row, normalised independently in ONE launch (G = 2: the q and k blocks of
+// a qkv row with weights w / w2 -- InternViT's q_norm + k_norm, modeling_intern_vit.py:131-134)
 int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
-                     long rows, int C, float eps, hipStream_t st);
+                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2 = nullptr, int G = 1);
 
 struct AttnArgs {
     const uint16_t *q, *k, *v;  // element pointers; D contiguous

@@ -27,17 +27,23 @@ template <bool RMS, int WPR, int MAXCH>
 __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t *__restrict__ x, int ldx,
                                                                  const uint16_t *__restrict__ w,
                                                                  const uint16_t *__restrict__ b, uint16_t *__restrict__ y,
-                                                                 int ldy, long rows, int C, float eps)
+                                                                 int ldy, long rows, int C, float eps,
+                                                                 const uint16_t *__restrict__ w2, int G)
 {
+    // G column groups of C elements per memory row (G = 2: the q and k blocks of a qkv row, weights w / w2): the kernel's
+    // "rows" are (memory row, group) pairs
     __shared__ float red[4][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rows_per_block = 4 / WPR;
     const int rloc = wave / WPR, wsub = wave % WPR;
     const long row = (long)blockIdx.x * rows_per_block + rloc;
     const bool live = row < rows;
-    const long r = live ? row : rows - 1;
+    const long rv = live ? row : rows - 1;
+    const long r = G == 1 ? rv : rv / G;
+    const int grp = G == 1 ? 0 : (int)(rv - r * G);
+    if (grp) w = w2;
     const int nchunk = C >> 3;
-    const uint16_t *xr = x + r * (long)ldx;
+    const uint16_t *xr = x + r * (long)ldx + (long)grp * C;
 
     uint4_t v[MAXCH];
     float s = 0.f, ss = 0.f;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
         rstd = rsqrtf(var / (float)C + eps);
     }
     if (!live) return;
-    uint16_t *yr = y + r * (long)ldy;
+    uint16_t *yr = y + r * (long)ldy + (long)grp * C;
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c = (i * WPR + wsub) * 64 + lane;
@@ -127,10 +133,12 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
 }
 
 int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
-                     long rows, int C, float eps, hipStream_t st)
+                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2, int G)
 {
     if (rows == 0) return VLLM_OK;
     VLLM_REQUIRE(x && w && y, "norm: null pointer");
+    VLLM_REQUIRE(G == 1 || (G == 2 && w2 && aligned16(w2) && !b), "norm: column groups: G = 2 with a second weight and no bias");
+    rows *= G;
     VLLM_REQUIRE(C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w) &&
                      (!b || aligned16(b)),
                  "norm: C and row strides must be multiples of 8 elements and pointers 16-byte aligned (C=%d)", C);
@@ -144,7 +152,7 @@ int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, co
     const int maxch = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 8;
     const int rpb = 4 / wpr;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(NORM_THREADS);
-#define L3(R, W, M) VLLM_LAUNCH((norm_bf16_kernel<R, W, M>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps)
+#define L3(R, W, M) VLLM_LAUNCH((norm_bf16_kernel<R, W, M>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps, w2, G)
 #define L2(R, W) do { if (maxch == 1) L3(R, W, 1); else if (maxch == 2) L3(R, W, 2); else if (maxch == 4) L3(R, W, 4); else L3(R, W, 8); } while (0)
     if (rms) { if (wpr == 1) L2(true, 1); else if (wpr == 2) L2(true, 2); else L2(true, 4); }
     else     { if (wpr == 1) L2(false, 1); else if (wpr == 2) L2(false, 2); else L2(false, 4); }

@@ -109,8 +109,12 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         prof_mark(PT_QKV, st);
         TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C));
         if (L.q_norm_w || L.k_norm_w) prof_mark(PT_QKNORM, st);
-        if (L.q_norm_w) TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st));
-        if (L.k_norm_w) TRY(norm_bf16_launch(true, qkv + C, 3 * C, L.k_norm_w, nullptr, qkv + C, 3 * C, M, C, d->eps, st));
+        if (L.q_norm_w && L.k_norm_w) {   // both (InternViT-6B): one launch over the [M, 2C] slab, q / k weight per column group
+            TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st, L.k_norm_w, 2));
+        } else {
+            if (L.q_norm_w) TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st));
+            if (L.k_norm_w) TRY(norm_bf16_launch(true, qkv + C, 3 * C, L.k_norm_w, nullptr, qkv + C, 3 * C, M, C, d->eps, st));
+        }
         {
             AttnArgs a;
             a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.out = ao;
