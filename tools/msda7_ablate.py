@@ -4,7 +4,7 @@ import ctypes, glob, os, re, sys, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from msda_inputs import CFG4_SHAPES, make_inputs
-NAMES = {0: "full", 1: "no gather FMAs", 2: "no gather LDS reads", 3: "no gather reads + FMAs (addressing / broadcasts kept)", 4: "no window DMA",
+NAMES = {9000: "HEAD before this change (round-2 DMA rounds)", 1024: "round-2 placement: DMA round BETWEEN gather points", 1028: "round-2 placement, no window DMA", 128: "DMA addresses computed, no load issued", 256: "DMA from the zero line only", 0: "full", 1: "no gather FMAs", 2: "no gather LDS reads", 3: "no gather reads + FMAs (addressing / broadcasts kept)", 4: "no window DMA",
          8: "no stores", 16: "no gather", 20: "no gather, no DMA", 28: "no gather / DMA / stores", 64: "no barrier", 6: "no reads, no DMA",
          92: "no gather / DMA / stores / barrier"}
 libs = {}

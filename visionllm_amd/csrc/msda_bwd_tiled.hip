@@ -18,6 +18,12 @@
 #include "kernels.hpp"
 #include "msda_sample.hpp"
 
+// Timing-only ablation builds (tools/msda_bwd_ablate.sh): -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (cold-window) atomics,
+// 4: no LDS adds, 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no window clear, 64: no flush loop.
+#ifndef BT_ABL
+#define BT_ABL 0
+#endif
+
 namespace vllm {
 namespace {
 
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             const bool use_lds = npix <= BT_WIN;   // block-uniform
 
             // ---- B: clear the accumulation window ----
-            if (use_lds) {
+            if (use_lds && !(BT_ABL & 32)) {
                 for (int i = tid; i < npix * 8; i += BT_THREADS) reinterpret_cast<float4_t *>(gwin)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
@@ -188,10 +194,11 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
         const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);                                        \
         const long g1 = ((long)h0 * W + x0) * MD, g2 = ((long)h0 * W + x1) * MD;                                       \
         const long g3 = ((long)h1 * W + x0) * MD, g4 = ((long)h1 * W + x1) * MD;                                       \
-        const float4_t v1 = *reinterpret_cast<const float4_t *>(vl + g1);                                             \
-        const float4_t v2 = *reinterpret_cast<const float4_t *>(vl + g2);                                             \
-        const float4_t v3 = *reinterpret_cast<const float4_t *>(vl + g3);                                             \
-        const float4_t v4 = *reinterpret_cast<const float4_t *>(vl + g4);                                             \
+        const float4_t zz = {0.f, 0.f, 0.f, 0.f};                                                                     \
+        const float4_t v1 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g1);                          \
+        const float4_t v2 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g2);                          \
+        const float4_t v3 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g3);                          \
+        const float4_t v4 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g4);                          \
         /* window element offsets (LDS path) / global pointers (fallback path) of the four corners */                 \
         const int e1 = ((h0 - y0) * ww + (x0 - x0w)) * 32 + sub * 4, e2 = ((h0 - y0) * ww + (x1 - x0w)) * 32 + sub * 4; \
         const int e3 = ((h1 - y0) * ww + (x0 - x0w)) * 32 + sub * 4, e4 = ((h1 - y0) * ww + (x1 - x0w)) * 32 + sub * 4; \
@@ -203,11 +210,12 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             const float ghw = -hw * a1 - lw * a2 + hw * a3 + lw * a4;                                                  \
             const float gww = -hh * a1 + hh * a2 - lh * a3 + lh * a4;                                                  \
             if (use_lds) {                                                                                             \
+                if (BT_ABL & 4) { g_aw += w1 * tgv; } else                                                            \
                 if (k1) lds_add(e1 + c, w1 * tgv);                                                                     \
                 if (k2) lds_add(e2 + c, w2 * tgv);                                                                     \
                 if (k3) lds_add(e3 + c, w3 * tgv);                                                                     \
                 if (k4) lds_add(e4 + c, w4 * tgv);                                                                     \
-            } else {                                                                                                   \
+            } else if (!(BT_ABL & 2)) {                                                                              \
                 if (k1) unsafeAtomicAdd(d1 + c, w1 * tgv);                                                             \
                 if (k2) unsafeAtomicAdd(d2 + c, w2 * tgv);                                                             \
                 if (k3) unsafeAtomicAdd(d3 + c, w3 * tgv);                                                             \
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
         _Pragma("unroll") for (int o = 4; o > 0; o >>= 1) {                                                            \
             g_aw += __shfl_xor(g_aw, o); g_x += __shfl_xor(g_x, o); g_y += __shfl_xor(g_y, o);                         \
         }                                                                                                              \
-        if (sub == 0 && pok) {   /* rejected points keep the caller's zero fill */                                     \
+        if (sub == 0 && pok && !(BT_ABL & 16)) {   /* rejected points keep the caller's zero fill */                                     \
             const long pi = (qidx[p] * L + l) * PT + K;                                                                \
             grad_attw[pi] = g_aw;                                                                                      \
             grad_loc[2 * pi] = g_x;                                                                                    \
@@ -243,14 +251,14 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             // ---- D: flush the window: one atomic per (pixel, channel), 128 contiguous bytes per pixel ----
             float *gflush = grad_value + lbase;
             const unsigned ww_magic = (1u << 20) / (unsigned)ww + 1u;   // pix / ww exact for pix * ww < 2^20
-            for (int i = tid; i < npix * 8; i += BT_THREADS) {
+            for (int i = tid; i < ((BT_ABL & 64) ? 0 : npix * 8); i += BT_THREADS) {
                 const int pix = i >> 3, c4 = (i & 7) * 4;
                 const int wy = (int)(((unsigned)pix * ww_magic) >> 20), wx = pix - wy * ww;
                 const float4_t v = reinterpret_cast<const float4_t *>(gwin)[i];
                 float *g = gflush + ((long)(y0 + wy) * W + (x0w + wx)) * MD + c4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (v[c] != 0.f) unsafeAtomicAdd(g + c, v[c]);
+                    if (v[c] != 0.f && !(BT_ABL & 1)) unsafeAtomicAdd(g + c, v[c]);
             }
         }
     }
@@ -286,5 +294,15 @@ int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64
     VLLM_CHECK_LAUNCH("msda_bwd_tiled_kernel");
     return VLLM_OK;
 }
+
+#ifdef BT_ABL_ENTRY
+extern "C" int bt_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw, void *stream)
+{
+    return msda_bwd_tiled_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
+}
+void set_error(const char *, ...) {}
+int msda_tiled_enabled() { return 1; }
+#endif
 
 }  // namespace vllm

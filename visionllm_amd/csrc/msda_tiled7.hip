@@ -26,9 +26,13 @@
 
 // Timing-only ablation builds (tools/msda7_ablate.sh): -DT7_ABL=<mask> removes one cost at a time; results are wrong by
 // construction.  1: no multiply-adds in the gather, 2: no LDS reads in the gather, 4: no window DMA, 8: no output stores,
-// 16: no gather at all, 64: no per-item barrier.
+// 16: no gather at all, 64: no per-item barrier, 128: window DMA addresses computed but no load issued, 256: window DMA
+// reads the zero line only (issue + LDS write cost without value traffic), 512: no point arithmetic / box reduction (constant points).
 #ifndef T7_ABL
 #define T7_ABL 0
+#endif
+#ifndef T7_OLD_PLACEMENT      // 1: a DMA round BETWEEN two gather points (round 2); 0: inside a point, under its LDS reads
+#define T7_OLD_PLACEMENT 0
 #endif
 
 namespace vllm {
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         }
         // (b) next's windows beside cur's
         int layn, late_n = -1, late_np_n = 0, used_next = 0;
+        int cum[5] = {0, 0, 0, 0, 0};   // pixels of next's HOT windows up to level l (wave-uniform): the DMA rounds walk their concatenation
         {
             const int limit = R - used_cur;
             int lay[4];
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
                 const int base = side ? R - used_next - np : used_next;
                 lay[l] = fits ? (base | (1 << 24)) : late ? (1 << 26) : (np > 0 ? (1 << 25) : 0);
                 used_next += fits ? np : 0;
+                cum[l + 1] = used_next;
                 late_np_n = late ? np : late_np_n;
                 late_n = late ? l : late_n;
             }
@@ -277,42 +283,44 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             }
         }
 
-        // ---- window DMA of next, one round (8 pixels per wave) per call, issued between the points of the gather ----
-        // All of the round's state is wave-uniform (SGPRs); the lane's pixel is re-derived from the round's first pixel.
-        int dl = -1, di0 = 0, dnpix = 0;              // level, first pixel of this wave's next round, pixels of the level
-        int dy0 = 0, dx0 = 0, dww = 1, dH = 1, dW = 1;
-        unsigned dmagic = 0;
-        const float *dsrc = value;                    // level base of (b, head)
-        char *ddst = smem;
+        // ---- window DMA of next, one round (8 pixels per wave) per call, issued under the LDS reads of the gather ----
+        // Round 3: the hot windows of the item are ONE concatenated list of 8-pixel groups (windows are padded to 8 pixels),
+        // group g belongs to wave g % NW; a round is straight-line code on scalars (group -> level by three compares against
+        // the cumulative pixel counts, the level's box / base / magic by v_readlane with that scalar) + ~12 VALU for the
+        // lane's pixel.  The source is a raw BUFFER load (descriptor = the level's slab of this (batch, head)): a pixel of
+        // the out-of-map ring gets an offset beyond the descriptor's size and the hardware returns zeros -- no zero line, no
+        // 64-bit address arithmetic, no select between two bases.  (The round-2 form kept per-level loop state that the
+        // compiler turned into VGPRs under exec masks: 83 s_and_saveexec in the kernel; ablation builds put the DMA's
+        // address work at 88 us of 518, profiles/r03_msda7_ablation.txt.)
+        int dg = wave_s;                              // this wave's next group
         const int lpx = lane >> 3;
+        // (readfirstlane: every value below IS wave-uniform, but the compiler's divergence analysis loses that somewhere in the
+        //  item loop and would keep the state in VGPRs under exec masks and wrap the load in a waterfall loop)
+        auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
         auto dma_round = [&]() {
-            while (dl < L && di0 >= dnpix) {           // next level with work for this wave
-                ++dl;
-                if (dl >= L) break;
-                const int lay_l = __builtin_amdgcn_readlane(layn, dl);
-                dnpix = 0; di0 = 0;
-                if (!((lay_l >> 24) & 1)) continue;
-                dy0 = __builtin_amdgcn_readlane(bxn.x, dl);
-                const int ny1 = __builtin_amdgcn_readlane(bxn.y, dl);
-                dx0 = __builtin_amdgcn_readlane(bxn.z, dl);
-                const int nx1 = __builtin_amdgcn_readlane(bxn.w, dl);
-                dww = (-nx1 + 1) - dx0 + 1;
-                dnpix = ((-ny1 + 1) - dy0 + 1) * dww; di0 = wave_s * 8;
-                dH = H0 >> dl; dW = W0 >> dl;
-                dmagic = (unsigned)__builtin_amdgcn_readlane((int)magick, dl);
-                dsrc = vbn + (size_t)__builtin_amdgcn_readlane(v0k, dl) * MD;
-                ddst = smem + (T6_ZPX + (lay_l & 0xffff)) * 128;
-            }
-            if (dl >= L) return;
-            if (T7_ABL & 4) { di0 += QPP; return; }
-            const int pix = di0 + lpx;
-            const int wy = (int)(((unsigned)pix * dmagic) >> 20), wx = pix - wy * dww;
-            const int gy = dy0 + wy, gx = dx0 + wx;
-            const bool inside = (unsigned)gy < (unsigned)dH && (unsigned)gx < (unsigned)dW;
-            const float *src = inside ? dsrc + (size_t)((unsigned)(gy * dW + gx) * MD) + sub8 * 4 : g_t6_zero_px + sub8 * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(ddst + di0 * 128), 16, 0, 0);
-            di0 += QPP;
+            const int p0 = uni(dg) * 8, c1 = uni(cum[1]), c2 = uni(cum[2]), c3 = uni(cum[3]), c4 = uni(cum[4]);
+            if (p0 >= c4) return;                     // (wave-uniform)
+            dg += NW;
+            if (T7_ABL & 4) return;
+            const int l = (p0 >= c1) + (p0 >= c2) + (p0 >= c3);
+            const int pix0 = p0 - (l == 0 ? 0 : l == 1 ? c1 : l == 2 ? c2 : c3);
+            const int lay_l = __builtin_amdgcn_readlane(layn, l);
+            const int y0 = __builtin_amdgcn_readlane(bxn.x, l), x0 = __builtin_amdgcn_readlane(bxn.z, l);
+            const int ww = (-__builtin_amdgcn_readlane(bxn.w, l) + 1) - x0 + 1;
+            const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick, l);
+            const int Hl = uni(H0) >> l, Wl = uni(W0) >> l;
+            const uint64_t lvl = (uint64_t)(uintptr_t)vbn + (uint64_t)(unsigned)__builtin_amdgcn_readlane(v0k, l) * (uint64_t)uni((int)MD) * 4u;
+            const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
+                                                                                 (int)(((unsigned)(Hl * Wl - 1) * (unsigned)uni((int)MD) + 32u) * 4u), 0x00020000);
+            const int pix = pix0 + lpx;
+            const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
+            const int gy = y0 + wy, gx = x0 + wx;
+            const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl && !(T7_ABL & 256);
+            const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
+            if (T7_ABL & 128) { asm volatile("" :: "v"(voff)); return; }
+            char *dst = smem + (size_t)(T6_ZPX + (lay_l & 0xffff) + pix0) * 128;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff, 0, 0, 0);
         };
 
         float acc[8];
@@ -323,7 +331,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             // The eight 16-byte reads of a point are ONE asm statement (reads + their wait): left to the compiler, a ds_read
             // behind an LDS-DMA in flight gets an s_waitcnt vmcnt(0) in front of it (the DMA "may alias" it), which would
             // serialise the next item's window DMA with this item's gather.  Which arena a read touches is ours to know.
-#define T7_HOT_POINT(I_, LQ)                                                                                     \
+            // Round 3: the reads of a point are issued FIRST and everything that does not need their data -- the DPP
+            // broadcasts of the point's four weights, and every second point one round of the next item's window DMA (its
+            // address arithmetic: ~18 VALU) -- runs in the shadow of the LDS round trip, in front of the wait.  Before, a DMA
+            // round sat BETWEEN two points: its VALU delayed the next point's reads by ~70 cycles per wave and the LDS pipe
+            // (the unit the gather is bound by) ran dry -- the ablation builds (profiles/r03_msda7_ablation.txt) put the
+            // cost of the address arithmetic alone at 88 us of 518, of issuing the DMA at 13 us.
+#define T7_HOT_POINT(I_, LQ, MID)                                                                                \
     {                                                                                                            \
         const int b0 = qbi<LQ>(oc[I_]) + cA0, b1 = b0 ^ 64;                                                       \
         const int b0p = b0 + pitch, b1p = b1 + pitch;                                                            \
@@ -332,12 +346,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:128\n\t"                                 \
                      "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:128\n\t"                                 \
                      "ds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:128\n\t"                               \
-                     "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:128\n\t"                               \
-                     "s_waitcnt lgkmcnt(0)"                                                                      \
+                     "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:128"                                   \
                      : "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4)    \
                      : "v"(b0), "v"(b0p), "v"(b1), "v"(b1p)                                                      \
                      : "memory");                                                                                \
         const float e1 = qbf<LQ>(w1c[I_]), e2 = qbf<LQ>(w2c[I_]), e3 = qbf<LQ>(w3c[I_]), e4 = qbf<LQ>(w4c[I_]);  \
+        MID;                                                                                                     \
+        /* the data registers are in / out operands of the wait: no consumer (nor a copy) can be placed above it */ \
+        if (!(T7_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
+                     : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4) :: "memory"); \
         if (T7_ABL & 1) { acc[0] += a1[0] + a2[1] + a3[2] + a4[3] + e1; acc[4] += c1[0] + c2[1] + c3[2] + c4[3] + e2 + e3 + e4; } else \
         _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                       \
             float2_t t = {acc[c], acc[c + 1]};                                                                   \
@@ -357,12 +374,19 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
 #define T7_LEVEL(LQ)                                                                                             \
     if (((__builtin_amdgcn_readlane(layc, LQ) >> 24) & 5) == want) {                                             \
         const int pitch = ((-__builtin_amdgcn_readlane(bxc.w, LQ) + 1) - __builtin_amdgcn_readlane(bxc.z, LQ) + 1) * 128; \
-        T7_HOT_POINT(0, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
-        T7_HOT_POINT(1, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_round();                                                                                             \
-        T7_HOT_POINT(2, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
-        T7_HOT_POINT(3, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_round();                                                                                             \
+        if (T7_OLD_PLACEMENT) {                                                                                  \
+            T7_HOT_POINT(0, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            T7_HOT_POINT(1, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            dma_round();                                                                                         \
+            T7_HOT_POINT(2, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            T7_HOT_POINT(3, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            dma_round();                                                                                         \
+        } else {                                                                                                 \
+            T7_HOT_POINT(0, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            T7_HOT_POINT(1, LQ, dma_round()) __builtin_amdgcn_sched_barrier(0);                                  \
+            T7_HOT_POINT(2, LQ, (void)0) __builtin_amdgcn_sched_barrier(0);                                      \
+            T7_HOT_POINT(3, LQ, dma_round()) __builtin_amdgcn_sched_barrier(0);                                  \
+        }                                                                                                        \
     }
             for (int pass = 0; pass < ((T7_ABL & 16) ? 0 : 2); ++pass) {
                 const int want = pass ? 5 : 1;   // hot levels; then the late one, behind its DMA + a barrier
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             T7_TICK(8)   // cold levels
         }
         // whatever is left of next's windows (all of them for the first item of the block)
-        while (dl < L) dma_round();
+        while (__builtin_amdgcn_readfirstlane(dg) * 8 < __builtin_amdgcn_readfirstlane(cum[4])) dma_round();
         T7_TICK(9)   // remaining DMA issue
         if (cv) {
             if (qokc && !(T7_ABL & 8)) {
