@@ -244,6 +244,19 @@ int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, u
                    int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
                    const uint16_t *scale, const uint16_t *res, int ldr, int P, vllm_stream_t stream);
 
+/* The same GEMM with caller-provided scratch for the stream-K tail of the 8-phase schedule: when the tiles of a GEMM do not
+ * fill a whole number of rounds on the device's CUs, the K iterations of the last round's tiles are spread evenly over all CUs
+ * (fp32 partial tiles meet in `scratch`, summed in a fixed order: results are run-to-run identical).  `scratch` is
+ * vllm_gemm_scratch_bytes() bytes, 16-byte aligned, its first 4096 bytes ZERO before the first call (the kernel leaves them
+ * zero); calls sharing a scratch must be ordered on one stream.  NULL scratch = vllm_gemm_bf16.  vllm_vit_forward /
+ * vllm_bridge_forward reserve theirs inside their workspace. */
+long vllm_gemm_scratch_bytes(void);
+long vllm_gemm_sk_launches(void);   /* GEMM launches of this process that took the stream-K tail (tests / tuning) */
+int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
+                      int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
+                      const uint16_t *scale, const uint16_t *res, int ldr, int P,
+                      void *scratch, long scratch_bytes, vllm_stream_t stream);
+
 /* B5: InternRMSNorm / apex FusedRMSNorm (modeling_intern_vit.py:33-58): y = w * bf16(x * rsqrt(mean(x^2)+eps)).
  * Row strides allow the in-place QK-RMSNorm over the q / k column blocks of the qkv buffer (:131-134). */
 int vllm_rmsnorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, uint16_t *y, int ldy,

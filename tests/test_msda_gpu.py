@@ -126,7 +126,7 @@ def test_tiled_kernel_matches_gather_kernel(mode):
     try:
         plain = _run(g)
         ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-        for variant in (1, 17, 2, 3, 5, 8, 9):  # automatic (generation 7 on pyramids, else 4); 17: generation 6; (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
+        for variant in (1, 18, 17, 2, 3, 5, 8, 9):  # automatic (generation 7 on pyramids, else 4); 17: generation 6; (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
             _lib.set_option("msda_tiled", variant)
             tiled = _run(g)
             again = _run(g)
@@ -172,7 +172,7 @@ def test_generation6_pyramid_items(name, mode):
     try:
         plain = _run(g)
         res = {}
-        for variant in (1, 17):   # automatic = generation 7 (software pipeline across items); generation 6
+        for variant in (1, 18, 17):   # automatic = generation 7 (software pipeline across items); generation 8 (two teams); generation 6
             _lib.set_option("msda_tiled", variant)
             res[variant] = (_run(g), _run(g))
     finally:

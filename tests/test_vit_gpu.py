@@ -172,6 +172,73 @@ def test_gemm256_epilogue_paths_agree(epi, force, M, N):
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
 
 
+os.environ.setdefault("VLLM_GEMM_SK_FIX", "0")   # tests: the stream-K tail wherever it is possible (the default charges its fix-up)
+
+
+def _sk_scratch():
+    n = _lib.lib().vllm_gemm_scratch_bytes()
+    return torch.zeros(n, dtype=torch.uint8, device=DEV), n
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024),      # 64 tiles on 256 CUs: every tile is shared by four blocks
+                                   (23080, 1024, 1024),     # proj: one whole round + a 108-tile tail
+                                   (23080, 3072, 1024),     # qkv: 12 column tiles, 91 = 8 * 11 + 3 row tiles -> the dense order's last partial group
+                                   (23080, 1024, 4096),     # fc2: 64 K iterations per tile, segments from the middle of a tile
+                                   (5000, 2056, 640)])      # ragged M / N edges (last column tile 8 wide)
+@pytest.mark.parametrize("epi", [0, 2, 3])
+@pytest.mark.parametrize("force", [0, 0x200, 0x300, 0x800])
+def test_gemm256_stream_k_tail(M, N, K, epi, force):
+    """Stream-K tail of the 8-phase schedule (scratch given): equal to the one-block-per-tile launch up to the fp32 summation
+    order of the K segments, within the same bound against the fp64 reference, and run-to-run bit-identical (the partial
+    tiles are added in a fixed order).  LayerScale'd and plain residual epilogues, activation, ragged edges."""
+    torch.manual_seed(M + N + K + epi)
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    ls = bf(0.1 + 0.05 * torch.randn(N, device=DEV)) if (M + epi) % 2 else None    # with / without LayerScale (residual as accumulator init)
+    res = bf(torch.randn(M, N, device=DEV))
+    scratch, nbytes = _sk_scratch()
+    L = _lib.lib()
+    args = (P(x), P(w), P(b))
+    tail = (M, N, K, K, K, N, epi | force, P(ls) if (epi == 3 and ls is not None) else None, P(res) if epi == 3 else None, N, 0)
+    before = L.vllm_gemm_sk_launches()
+    ys = []
+    for _ in range(3):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.vllm_gemm_bf16_sk(*args, P(y), *tail, P(scratch), nbytes, stream()))
+        ys.append(y)
+    took = L.vllm_gemm_sk_launches() - before
+    y0 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.vllm_gemm_bf16(*args, P(y0), *tail, stream()))
+    torch.cuda.synchronize()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    def tail_ok(rows):   # the launcher's rule with VLLM_GEMM_SK_FIX=0 (gemm256.hip): an incomplete last round, >= 1 K iteration per block
+        r = (-(-M // rows) * -(-N // 256)) % cus
+        return 0 < r <= cus * 15 // 16 and r * (K // 64) >= cus
+    if force in (0x200, 0x800):
+        assert took == (3 if tail_ok(256) else 0), f"stream-K launches: {took}"
+    elif force == 0x300:
+        assert took == (3 if tail_ok(192) else 0), f"stream-K launches: {took}"
+    else:
+        assert took in (0, 3)
+    assert (scratch[:4096] == 0).all(), "flags must be left zero"
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), "stream-K: runs differ"
+    assert torch.isfinite(ys[0].float()).all()
+    z = x.double() @ w.double().t() + b.double()
+    mag = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    if epi == 2:
+        z = z * torch.sigmoid(1.702 * z)
+    elif epi == 3:
+        lsd = ls.double() if ls is not None else 1.0
+        z = res.double() + z * lsd
+        mag = res.double().abs() + mag * (ls.double().abs() if ls is not None else 1.0)
+    ulp_close(ys[0], z, 1.0, mag, 2.0 ** -17, f"gemm stream-K epi={epi} force={force:#x} M{M} N{N} K{K}")
+    # against the one-block-per-tile result: the same products, another fp32 summation order -> at most one bf16 ulp apart, rarely
+    d = (ys[0].float() - y0.float()).abs()
+    assert (d <= 2.0 * bf16_ulp(y0.float()).float().to(d.device) + 2.0 ** -17 * mag.float().to(d.device)).all()
+    assert (ys[0] != y0).float().mean().item() < 0.02
+
+
 def test_gemm_rejects_bad_shapes():
     x = bf(torch.zeros(4, 100, device=DEV))
     with pytest.raises(RuntimeError):

@@ -318,3 +318,24 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
 }
+
+extern "C" long vllm_gemm_scratch_bytes(void) { return SK_SCRATCH_BYTES; }
+namespace vllm { long gemm256_sk_launches(); }
+extern "C" long vllm_gemm_sk_launches(void) { return vllm::gemm256_sk_launches(); }
+
+extern "C" int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y, int M, int N,
+                                 int K, int ldx, int ldw, int ldy, int epilogue, const uint16_t *scale,
+                                 const uint16_t *res, int ldr, int P, void *scratch, long scratch_bytes, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(X && W && Y, "vllm_gemm_bf16_sk: null pointer");
+    VLLM_REQUIRE(!scratch || (scratch_bytes >= SK_FLAG_BYTES + SK_SLOT_BYTES && aligned16(scratch)), "vllm_gemm_bf16_sk: scratch too small or misaligned");
+    GemmArgs a;
+    gemm_set_scratch(a, scratch, scratch_bytes);
+    a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
+    if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;
+    if (epilogue & 0x800) a.variant = 4;
+    if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }
+    else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
+    return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
+}

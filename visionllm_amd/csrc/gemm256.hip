@@ -82,15 +82,73 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     static_assert(!MF32 || MT == 4, "32x32x16 path: 256-row tiles only");
     typedef float f32x16_t __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    GemmArgs al = a0_;            // (block-local copy: res_init may be switched off for this block, see below)
-    const GemmArgs &a = al;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     const int wr = wave >> 2, wc = wave & 3;
+    const int nk_all = a0_.K / G2_BK;
+
+    // ---- work of this block: one whole tile, or (stream-K tail, see the launcher) up to two K segments of adjacent tiles ----
+    // The K iterations of the sk_tiles last tiles form ONE list of sk_tiles * nk entries that sk_blocks blocks share evenly:
+    // block `rid` owns [rid * total / sk_blocks, (rid + 1) * total / sk_blocks) -- fewer entries than a tile has, so at most
+    // the tail of one tile and the head of the next.  A segment that does not reach its tile's last K iteration leaves its raw
+    // fp32 accumulators in scratch slot `rid` (PARTIAL); the block that owns the last iteration of a tile adds the slots of
+    // everyone in front of it, in ascending order (deterministic), and runs the epilogue.  A block does its PARTIAL segment
+    // first: nobody waits for a block that is itself waiting.
+    int seg_t0 = -1, seg_t1 = -1, seg_k0a = 0, seg_k0b = 0, seg_na = nk_all, seg_nb = 0, nseg = 1, rid = 0;
+    if (a0_.sk_tiles > 0) {
+        if ((int)blockIdx.x < a0_.sk_dp) {
+            seg_t0 = blockIdx.x;
+        } else {
+            const int sb = blockIdx.x - a0_.sk_dp;
+            rid = (sb & 7) * (a0_.sk_blocks >> 3) + (sb >> 3);     // neighbours in the list sit on the same XCD (same L2)
+            const long total = (long)a0_.sk_tiles * nk_all;
+            const int it0 = (int)(rid * total / a0_.sk_blocks), it1 = (int)((rid + 1) * total / a0_.sk_blocks);
+            if (it1 <= it0) return;
+            const int tlo = it0 / nk_all, thi = (it1 - 1) / nk_all;
+            if (tlo == thi) {
+                seg_t0 = a0_.sk_dp + tlo; seg_k0a = it0 - tlo * nk_all; seg_na = it1 - it0;
+            } else {
+                nseg = 2;
+                seg_t0 = a0_.sk_dp + thi; seg_k0a = 0; seg_na = it1 - thi * nk_all;                        // head of the next tile: PARTIAL
+                seg_t1 = a0_.sk_dp + tlo; seg_k0b = it0 - tlo * nk_all; seg_nb = nk_all - seg_k0b;         // tail of this tile: finishes it
+            }
+        }
+    }
+    for (int seg = 0; seg < nseg; ++seg) {
+    // (the lane index is laundered per segment: nothing lane-dependent is loop-invariant, or the compiler hoists the per-lane
+    //  address arithmetic of prologue AND epilogue in front of the loop and spills it across the main loop)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     const int fr = lane & 15, kq = lane >> 4;
+    const int tid_l = wave * 64 + lane;
+    GemmArgs al = a0_;            // (block-local copy: res_init may be switched off for this block / segment, see below)
+    const GemmArgs &a = al;
+    const int tile_d = seg == 0 ? seg_t0 : seg_t1;
+    const int kbeg = seg == 0 ? seg_k0a : seg_k0b;
+    const int nk = seg == 0 ? seg_na : seg_nb;
+    const bool finishing = kbeg + nk == nk_all;
+    if (!finishing) al.res_init = 0;      // the residual (as the accumulators' initial value) enters once, in the finishing segment
 
     // ---- XCD-aware tile mapping (as gemm.hip) ----
     int tm_idx, tn_idx;
-    {
+    if (a.sk_tiles > 0) {
+        // dense order (no padding tiles): complete groups of 8 X panels first, mapped as below; then the last mt % 8 panels
+        if ((a.nt & 7) == 0) {
+            const int xcd = tile_d & 7, s = tile_d >> 3, npx = a.nt >> 3;
+            tn_idx = xcd + 8 * (s % npx);
+            tm_idx = s / npx;
+        } else {
+            const int fullp = (a.mt >> 3) * 8 * a.nt;
+            if (tile_d < fullp) {
+                const int xcd = tile_d & 7, s = tile_d >> 3;
+                tm_idx = xcd + 8 * (s / a.nt);
+                tn_idx = s % a.nt;
+            } else {
+                const int vx = a.mt & 7, e = tile_d - fullp;
+                tm_idx = (a.mt & ~7) + e % vx;
+                tn_idx = e / vx;
+            }
+        }
+    } else {
         const int tile = blockIdx.x, xcd = tile & 7, s = tile >> 3;
         if ((a.nt & 7) == 0) {
             const int npx = a.nt >> 3;
@@ -106,12 +164,11 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     const int m0 = tm_idx * BM_, n0 = tn_idx * G2_BN;
     const unsigned t_start = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     const unsigned long long rt_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int nk = a.K / G2_BK;
 
     // Residual as accumulator init (below) with a LayerScale needs 1 / ls: every block checks ITS 256 columns (finite, |ls| >=
     // 1e-4: the division must not blow the fp32 accumulation up) and keeps the plain epilogue otherwise -- block-uniform.
     if (EPI == EPI_RESIDUAL && al.res_init && al.scale) {
-        const int t = threadIdx.x;
+        const int t = tid_l;
         bool ok = true;
         if (t < G2_BN && n0 + t < al.N) {
             const float v = bf16_to_f32(al.scale[n0 + t]);
@@ -211,7 +268,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     bf16x8_t xf[MT][2], wf[2][2];   // MF32: xf[2 m blocks x 2][..] viewed as [jb*2 + ks/2][ks&1], wf[ks/2][ks&1]
     bf16x8_t xg[MF32 ? 2 : 1][2];   // MF32: third 16-register X buffer (see the MF32 loop)
 
-    auto k_of = [&](int t) { return (t < nk ? t : nk - 1) * G2_BK; };   // clamped: tail refills are harmless
+    auto k_of = [&](int t) { return (kbeg + (t < nk ? t : nk - 1)) * G2_BK; };   // clamped: tail refills are harmless
     auto issue_A = [&](int half, int stage, int t) {
         issue_half<4 * MT, MF32>(a.X, a.ldx, m0 + half * (32 * MT), a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0),
                            wave, lane, a.xP);
@@ -367,6 +424,82 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     if (wr == 0) G2_BARRIER();   // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
     const unsigned t_loop = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+    if (a.sk_tiles > 0 && (int)blockIdx.x >= a.sk_dp) {
+        // Hand-off between workgroups (cdna_hip_programming.md section 6, guideline 16, form R1): the payload is stored
+        // WRITE-THROUGH (sc1, 16 bytes per lane) and read back with sc1 loads, so neither side needs a cache-wide fence and
+        // nothing depends on which XCD a block runs on; every storing wave drains its stores, ONE lane publishes the flag
+        // (relaxed, agent scope); the reader polls that one word relaxed.  (A first version with __threadfence() in every
+        // thread and acquire polls cost ~100 us per GEMM: each is a walk over the XCD's L2.)
+        // scratch slot: 32 16-byte vectors per thread, vector v of thread t at (v * 512 + t) -> every access is a coalesced 8 KiB row
+        const __amdgpu_buffer_rsrc_t ws_rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sk_ws, 0, (int)(a.sk_blocks * (32 * G2_THREADS * 16)), 0x00020000);
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        constexpr int AUX_SC1 = 16;
+        if (!finishing) {
+            const int base = (rid * (32 * G2_THREADS) + tid_l) * 16;
+            if constexpr (MF32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4_t v = {acc32[q][jb][4 * g], acc32[q][jb][4 * g + 1], acc32[q][jb][4 * g + 2], acc32[q][jb][4 * g + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rs, base + ((q * 2 + jb) * 4 + g) * (G2_THREADS * 16), 0, AUX_SC1);
+                        }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[q][i][j]), ws_rs, base + ((q * 2 + i) * MT + j) * (G2_THREADS * 16), 0, AUX_SC1);
+            }
+            asm volatile("s_waitcnt vmcnt(0) ; stream-K publish: every storing wave drains" ::: "memory");
+            __syncthreads();
+            if (tid_l == 0) __hip_atomic_store(a.sk_flags + rid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        // finishing: the segments in front of this one, lowest K first
+        const long total = (long)a.sk_tiles * nk_all;
+        const long ts = (long)(tile_d - a.sk_dp) * nk_all;
+        int c = (int)(ts * a.sk_blocks / total);
+        while ((long)(c + 1) * total / a.sk_blocks <= ts) ++c;
+        for (; c < rid; ++c) {
+            if (tid_l == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.sk_flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 26)) __builtin_trap();   // (minutes: the producer is gone -- fail loudly instead of hanging the device)
+                }
+            }
+            __syncthreads();
+            const int base = (c * (32 * G2_THREADS) + tid_l) * 16;
+            // a quadrant (8 vectors = 32 registers) at a time: all 32 loads in flight at once would not fit beside the accumulators
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (MF32) {
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4_t p = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws_rs, base + ((q * 2 + jb) * 4 + g) * (G2_THREADS * 16), 0, AUX_SC1));
+                            acc32[q][jb][4 * g] += p[0]; acc32[q][jb][4 * g + 1] += p[1]; acc32[q][jb][4 * g + 2] += p[2]; acc32[q][jb][4 * g + 3] += p[3];
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+                            acc[q][i][j] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws_rs, base + ((q * 2 + i) * MT + j) * (G2_THREADS * 16), 0, AUX_SC1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                 // everyone has read slot c: its flag goes back to zero for the next launch
+            if (tid_l == 0) __hip_atomic_store(a.sk_flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     struct ProfEnd {
         const GemmArgs &a; unsigned t0, t1, t2; int w, l; unsigned long long rt0;
         __device__ ~ProfEnd() {
@@ -442,7 +575,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         }
         }
         __builtin_amdgcn_s_barrier();
-        const int t = threadIdx.x, c8 = (t & 31) * 8;   // 32 lanes x 16 B = one 512-byte tile row
+        const int t = tid_l, c8 = (t & 31) * 8;   // 32 lanes x 16 B = one 512-byte tile row
 #pragma unroll 4
         for (int p = 0; p < BM_ / 16; ++p) {
             const int ml = p * 16 + (t >> 5), m = m0 + ml, n = n0 + c8;
@@ -451,7 +584,8 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 *reinterpret_cast<uint4_t *>(a.Y + epi_out_row<EPI>(a, m) * a.ldy + n) = o;
             }
         }
-        return;
+        __syncthreads();   // (a second segment's prologue overwrites the ring)
+        continue;
     }
     if constexpr (MF32) {
 #pragma unroll
@@ -489,12 +623,33 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         }
     }
     }
+    }   // segments
 }
 
 static bool res_init_disabled()
 {
     static const int v = [] { const char *e = getenv("VLLM_GEMM_RES_INIT"); return e && e[0] == '0' ? 1 : 0; }();   // A/B switch
     return v != 0;
+}
+
+static long g_sk_launches = 0;   // launches that took the stream-K tail (vllm_gemm_sk_launches: tests assert the path they mean to cover ran)
+long gemm256_sk_launches() { return g_sk_launches; }
+
+// VLLM_GEMM_SK=0 switches the stream-K tail off (A/B); VLLM_GEMM_SK_MAX=<tiles> overrides the largest tail that takes it
+static bool sk_disabled()
+{
+    static const int v = [] { const char *e = getenv("VLLM_GEMM_SK"); return e && e[0] == '0' ? 1 : 0; }();
+    return v != 0;
+}
+static double sk_fixup_cost()   // VLLM_GEMM_SK_FIX=<units>: the fix-up's charge in the launcher's cost model (100 = one 256-row K = 1024 tile)
+{
+    static const double v = [] { const char *e = getenv("VLLM_GEMM_SK_FIX"); return e ? atof(e) : 130.0; }();
+    return v;
+}
+static long sk_max_tiles(int cus)
+{
+    static const long v = [] { const char *e = getenv("VLLM_GEMM_SK_MAX"); return e ? atol(e) : -1L; }();
+    return v >= 0 ? v : (long)cus * 15 / 16;
 }
 
 int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
@@ -539,17 +694,42 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 #endif
     // block rows 256 (MT=4) or 192 (MT=3): pick the one with the smaller (rounds x tile cost) on this many CUs
     // measured: a 192-row tile costs 0.87 of a 256-row tile (12 instead of 16 MFMAs per phase, same barriers)
-    auto rounds_cost = [&](long rows, int mt_rows) {
-        const long tiles = (long)ceil_div(rows, 64 * mt_rows) * a.nt;
-        return ((tiles + cus - 1) / cus) * (long)(mt_rows == 4 ? 100 : 87);
+    // Stream-K tail (when the caller provides scratch): the tiles of the last, incomplete round do not get a block each -- their
+    // K iterations are split evenly over `cus` blocks (kernel comment), so the round costs its share of a tile + the fix-up.
+    // The fix-up is NOT small on this part: every block writes one 256 KiB fp32 slot and reads one to three -- 128 MB through
+    // the fabric per launch, 30-45 us measured on the ViT-L shapes whatever K is (profiles/r03_gemm_stream_k.txt), i.e. more
+    // than a whole K = 1024 tile (33 us).  In units of that tile (100) the fix-up is charged 130, so the tail only takes the
+    // stream-K route when a tile is several times longer than that (K >= 4096 and a mostly empty last round).
+    // hipBLASLt picks the same macro tile with stream-K for these shapes (profiles/r03_hipblaslt_kernel_names.txt).
+    const int nk = a.K / G2_BK;
+    const bool sk_possible = a.sk_ws && a.sk_flags && a.sk_ws_bytes >= (long)cus * 32 * G2_THREADS * 16 && (cus & 7) == 0 &&
+                             aligned16(a.sk_ws) && !sk_disabled();
+    const double sk_fix = sk_fixup_cost();
+    auto plan = [&](int mt_rows, int *sk_tiles) -> double {
+        const long T = (long)ceil_div(a.M, 64 * mt_rows) * a.nt;
+        const long full = T / cus, r = T % cus;
+        const double c = (mt_rows == 4 ? 100.0 : 87.0) * nk / 16.0;
+        *sk_tiles = 0;
+        if (r == 0) return (double)full * c;
+        const double dp = (double)(full + 1) * c, sk = ((double)full + (double)r / cus) * c + sk_fix;
+        if (sk_possible && r * nk >= cus && r <= sk_max_tiles(cus) && sk < dp) { *sk_tiles = (int)r; return sk; }
+        return dp;
     };
-    int MT = rounds_cost(a.M, 3) < rounds_cost(a.M, 4) ? 3 : 4;
+    int sk3 = 0, sk4 = 0;
+    const double c3 = plan(3, &sk3), c4 = plan(4, &sk4);
+    int MT = c3 < c4 ? 3 : 4;
     if (a.variant256 == 3 || a.variant256 == 4) MT = a.variant256;
     const bool mf32 = a.variant256 == 5;   // 256-row tiles on the 32x32x16 instruction
     if (mf32) MT = 4;
     a.mt = ceil_div(a.M, 64 * MT);
+    a.sk_tiles = MT == 3 ? sk3 : sk4;
     long tiles;
-    if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
+    if (a.sk_tiles > 0) {
+        ++g_sk_launches;
+        a.sk_dp = (int)((long)a.mt * a.nt - a.sk_tiles);
+        a.sk_blocks = cus;
+        tiles = (long)a.sk_dp + cus;
+    } else if ((a.nt & 7) == 0) tiles = (long)a.mt * a.nt;
     else tiles = (long)((a.mt + 7) / 8) * 8 * a.nt;
     // automatic = through LDS: interleaved, order-robust timing (tools/gemm_ab.py) has it at -13 % on qkv (5 rounds of
     // tiles), level on fc1 / fc2 / proj; splitting the rows into whole rounds + a tail launch was measured too and does

@@ -38,6 +38,14 @@ struct GemmArgs {
     int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
     int res_init = 0;       // EPI_RESIDUAL without LayerScale, 8-phase kernel: the residual is the accumulators' initial value (launcher)
     int prof = 0;           // VLLM_GEMM_PROF=1: the 8-phase kernel adds prologue / main loop / epilogue ticks to device counters
+    // Stream-K tail of the 8-phase kernel (gemm256.hip): scratch for fp32 partial tiles + one flag per scratch slot, provided by
+    // the caller (the orchestrators carve them out of their workspace; flags zeroed once per forward).  The launcher fills sk_*.
+    float *sk_ws = nullptr;
+    unsigned *sk_flags = nullptr;
+    long sk_ws_bytes = 0;
+    int sk_tiles = 0;       // tiles (the last ones of the dense order) whose K iterations are spread evenly over sk_blocks blocks
+    int sk_dp = 0;          // tiles in front of them: one block each, as without stream-K
+    int sk_blocks = 0;
     unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
                                            // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
 };
@@ -61,11 +69,24 @@ extern int g_prof_on;
 void prof_mark_slow(int tag, hipStream_t st);
 inline void prof_mark(int tag, hipStream_t st) { if (g_prof_on) prof_mark_slow(tag, st); }
 
+// Scratch of the 8-phase GEMM's stream-K tail: [4 KiB of flags, zero before the first use][SK_MAX_BLOCKS slots of 256 KiB].
+// The orchestrators reserve it in their workspace (and zero the flags once per forward); vllm_gemm_bf16_sk takes it from the caller.
+constexpr long SK_FLAG_BYTES = 4096, SK_SLOT_BYTES = 32L * 512 * 16, SK_MAX_BLOCKS = 320;
+constexpr long SK_SCRATCH_BYTES = SK_FLAG_BYTES + SK_MAX_BLOCKS * SK_SLOT_BYTES;
+inline void gemm_set_scratch(GemmArgs &a, void *scratch, long bytes)
+{
+    if (!scratch || bytes < SK_FLAG_BYTES + SK_SLOT_BYTES) return;
+    a.sk_flags = reinterpret_cast<unsigned *>(scratch);
+    a.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + SK_FLAG_BYTES);
+    a.sk_ws_bytes = bytes - SK_FLAG_BYTES;
+}
+
 inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint16_t *W, int ldw, const uint16_t *bias,
                 uint16_t *Y, int ldy, int M, int N, int K, const uint16_t *scale = nullptr, const uint16_t *res = nullptr,
-                int ldr = 0, int P = 0, int xP = 0)
+                int ldr = 0, int P = 0, int xP = 0, void *scratch = nullptr, long scratch_bytes = 0)
 {
     GemmArgs a;
+    gemm_set_scratch(a, scratch, scratch_bytes);
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = xP; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     return gemm_bf16_launch(epi, a, st);

@@ -12,7 +12,7 @@ namespace {
 inline long align256(long x) { return (x + 255) & ~255L; }
 
 struct VitWs {
-    long xn, qkv, ao, hmid, mid, col, h0, h1, total;
+    long xn, qkv, ao, hmid, mid, col, h0, h1, sk, total;
 };
 
 VitWs vit_ws_layout(const VllmVitDesc *d, int n)
@@ -29,6 +29,7 @@ VitWs vit_ws_layout(const VllmVitDesc *d, int n)
     w.col = take((long)n * P * d->kpad * 2);
     w.h0 = take(M * d->hidden * 2);   // ping-pong hidden states for entries the caller does not want
     w.h1 = take(M * d->hidden * 2);
+    w.sk = take(SK_SCRATCH_BYTES);    // stream-K tail of the GEMMs (kernels.hpp)
     w.total = off;
     return w;
 }
@@ -86,11 +87,14 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
 
     auto state = [&](int i) -> uint16_t * { return hs[i] ? hs[i] : pp[i & 1]; };
 
+    void *sk = ws + w.sk;
+    VLLM_REQUIRE(hipMemsetAsync(sk, 0, SK_FLAG_BYTES, st) == hipSuccess, "vit: flag reset failed");
+
     // ---- embeddings: im2col gather -> GEMM (+bias +pos, rows scattered past CLS) ; CLS rows ----
     uint16_t *emb = clip ? hmid : state(0);   // CLIP: pre_layrnorm produces hidden_states[0]
     prof_mark(PT_EMBED, st);
     TRY(im2col_launch(pixels, d->pixel_is_f32, col, n, d->image, d->patch, d->kpad, st));
-    TRY(gemm(st, EPI_EMBED, col, d->kpad, d->patch_w, d->kpad, d->patch_b, emb, C, n * P, C, d->kpad, nullptr, d->pos, C, P));
+    TRY(gemm(st, EPI_EMBED, col, d->kpad, d->patch_w, d->kpad, d->patch_b, emb, C, n * P, C, d->kpad, nullptr, d->pos, C, P, 0, sk, SK_SCRATCH_BYTES));
     TRY(cls_rows_launch(d->cls, d->pos, emb, n, S, C, st));
     if (clip) {
         VLLM_REQUIRE(d->pre_ln_w && d->pre_ln_b, "vit: CLIP needs pre_layrnorm");
@@ -107,7 +111,7 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         prof_mark(PT_NORM, st);
         TRY(norm_bf16_launch(!clip, h, C, L.norm1_w, L.norm1_b, xn, C, M, C, d->eps, st));
         prof_mark(PT_QKV, st);
-        TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C));
+        TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
         if (L.q_norm_w || L.k_norm_w) prof_mark(PT_QKNORM, st);
         if (L.q_norm_w && L.k_norm_w) {   // both (InternViT-6B): one launch over the [M, 2C] slab, q / k weight per column group
             TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st, L.k_norm_w, 2));
@@ -127,14 +131,14 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
             TRY(attn_fwd_launch(a, D, st));
         }
         prof_mark(PT_PROJ, st);
-        TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C));
+        TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C, 0, 0, sk, SK_SCRATCH_BYTES));
         // MLP block
         prof_mark(PT_NORM, st);
         TRY(norm_bf16_launch(!clip, hmid, C, L.norm2_w, L.norm2_b, xn, C, M, C, d->eps, st));
         prof_mark(PT_FC1, st);
-        TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C));
+        TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
         prof_mark(PT_FC2, st);
-        TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C));
+        TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C, 0, 0, sk, SK_SCRATCH_BYTES));
     }
     prof_mark(PT_END, st);
     return VLLM_OK;
@@ -142,7 +146,7 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
 
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-struct BridgeWs { long a, b, c, total; };
+struct BridgeWs { long a, b, c, sk, sk_bytes, total; };
 BridgeWs bridge_ws_layout(const VllmBridgeDesc *d, int n, int T_in)
 {
     const long T = d->pixel_shuffle ? T_in / 4 : T_in;
@@ -153,6 +157,8 @@ BridgeWs bridge_ws_layout(const VllmBridgeDesc *d, int n, int T_in)
     w.a = take(d->pixel_shuffle ? rows * d->in_features * 2 : 0);                       // shuffled features
     w.b = take(d->kind == VLLM_BRIDGE_INTERNVL_MLP ? rows * d->in_features * 2 : 0);   // LayerNorm output
     w.c = take(d->depth > 1 ? 2 * align256(rows * (long)d->out_features * 2) : 0);     // MLP intermediates
+    w.sk_bytes = rows >= 1024 ? SK_SCRATCH_BYTES : 0;                                   // stream-K tail of the 8-phase GEMM (kernels.hpp)
+    w.sk = take(w.sk_bytes);
     w.total = off;
     return w;
 }
@@ -206,6 +212,8 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
         x = ln; ldx = Cin;
     }
     uint16_t *tmp[2] = {(uint16_t *)(ws + w.c), (uint16_t *)(ws + w.c + align256(rows * (long)Cout * 2))};
+    void *sk = w.sk_bytes ? ws + w.sk : nullptr;
+    if (sk) VLLM_REQUIRE(hipMemsetAsync(sk, 0, SK_FLAG_BYTES, st) == hipSuccess, "bridge: flag reset failed");
     int K = Cin;
     for (int i = 0; i < d->depth; ++i) {
         VLLM_REQUIRE(d->w[i], "bridge: weight %d missing", i);
@@ -214,7 +222,7 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
         // GELU sits between Linear i and Linear i+1 -> fused into Linear i's epilogue
         prof_mark(PT_BRIDGE_GEMM, st);
         TRY(gemm(st, last ? EPI_BIAS : EPI_GELU, x, ldx, d->w[i], K, d->b[i], y, Cout, (int)rows, Cout, K, nullptr, nullptr,
-                 0, 0, i == 0 ? xP : 0));
+                 0, 0, i == 0 ? xP : 0, sk, w.sk_bytes));
         x = y; ldx = Cout; K = Cout;
     }
     prof_mark(PT_END, st);
