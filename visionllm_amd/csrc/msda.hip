@@ -607,6 +607,9 @@ bool msda_bwd_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, co
 int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                           const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
                           hipStream_t st);
+int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                         const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
+                         hipStream_t st);   // msda_bwd_mfma.hip
 }  // namespace vllm
 
 template <int LPG>
@@ -636,9 +639,14 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
     VLLM_REQUIRE((long)B * Lq == 0 || (value && shapes && lsi && loc && attw && grad_out && gv && gl && gw),
                  "msda_backward_f32: null pointer");
-    // encoder self-attention shape: grad_value accumulated per (query tile, level) window in LDS (msda_bwd_tiled.hip)
-    if ((long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv))
+    // encoder self-attention shape: grad_value per (query tile, level) window as S^T x grad_out on the matrix cores
+    // (msda_bwd_mfma.hip); VLLM_MSDA_BWD_LDS=1: the round-2 kernel that accumulates the window with LDS atomics (A/B)
+    if ((long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv)) {
+        static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
+        if (!lds_atomics)
+            return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
         return msda_bwd_tiled_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
+    }
     if ((long)B * Lq != 0 && D % 4 == 0 && (P == 1 || P == 2 || P == 4 || P == 8) && aligned16(value) &&
         aligned16(grad_out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0) {
         const int lpg = D / 4;

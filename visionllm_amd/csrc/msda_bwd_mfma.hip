@@ -1,25 +1,31 @@
-// MSDA backward, LDS-tiled variant for the encoder self-attention case (queries == pyramid pixels, Lq == S, D = 32, P = 4).
+// MSDA backward for the encoder self-attention case (queries == pyramid pixels, Lq == S, D = 32, P = 4), generation 2:
+// grad_value through the matrix cores.
+//
+// What the phase clock of msda_bwd_tiled.hip showed (profiles/r03_msda_bwd_phases.txt): 86 % of its 22 ms is the phase that
+// accumulates grad_value in LDS with ds_add_f32 -- 65 536 lane-atomics per (query tile, level), and the LDS retires a float
+// atomic every ~2 cycles per LANE, whatever the addresses.  But the scatter factors: for a tile of 128 queries and a window
+// of pixels
+//      grad_value[pix, ch] += sum_q  S[pix, q] * grad_out[q, ch],     S[pix, q] = sum over the 16 (point, corner) pairs of
+//                                                                     query q that land on pix of  attention weight x bilinear weight
+// -- the channel does not enter S.  So per (tile, level):
+//   (1) S^T [128 queries][128 window pixels] is built in LDS with 2 048 lane-atomics (one per (query, point, corner): 32x fewer),
+//   (2) a wave multiplies a 32-pixel chunk of it with grad_out [128 x 32] on v_mfma_f32_32x32x2_f32 (exact fp32; 64 steps of
+//       k = 2 queries; the B operand -- grad_out of the tile -- stays in 64 registers for all levels and rounds of the item),
+//   (3) and adds its 32 x 32 result to grad_value with one atomic per (pixel, channel), a wave instruction covering two whole
+//       128-byte pixel rows.
+// Windows larger than 128 pixels take several rounds of (1)-(3); beyond 1024 pixels (far-away samples) the level falls
+// back to direct global atomics per (point, corner, channel).  grad_sampling_loc and grad_attn_weight are computed as
+// before (value corners from global memory / L2, one owner per element, plain stores).
 //
 // Follows ms_deform_im2col_cuda.cuh:87-161 (col2im bilinear: grad_value scatter, grad_sampling_loc, grad_attn_weight) and
-// the shared-memory reductions of :301-360; the plain kernel (msda.hip, msda_bwd_vec_kernel) issues one hardware fp32
-// atomic per (point, corner, channel) straight to global memory -- 4.9 G scattered 4-byte atomics at the cfg-4 encoder
-// shape, which is what its 57 ms are.  Here a block owns an 8x16 tile of queries of ONE head (the forward kernel's
-// decomposition, msda_tiled.hip).  For each target level it
-//   (1) computes the exact bounding window of all corners its 128 x 4 sampling points touch,
-//   (2) accumulates grad_value for that window in LDS (ds_add_f32, window <= 560 pixels x 32 channels fp32),
-//   (3) flushes the window once: one atomic per (window pixel, channel), 128 contiguous bytes per pixel.
-// Neighbouring queries hit the same pixels, so the window holds ~4x fewer elements than there are (point, corner)
-// contributions, and the global atomics that remain are whole-line instead of 16-byte-strided.  grad_sampling_loc and
-// grad_attn_weight have exactly one owner (plain stores), the value corners they need are read from global memory / L2 as
-// in the plain kernel.  A level whose window does not fit falls back to direct global atomics for that (block, level):
-// correctness never depends on offsets being small.  Summation order differs from the plain kernel (both are atomic
-// scatters); tests compare against the oracle with the same tolerance.
+// the reductions of :301-360.  Summation order differs from the reference's atomics (as every atomic scatter does); tests
+// compare against the oracle with the tolerance of the other backward kernels.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "msda_sample.hpp"
 
-// Timing-only ablation builds (tools/msda_bwd_ablate.sh): -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (cold-window) atomics,
-// 4: no LDS adds, 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no window clear, 64: no flush loop.
+// Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (large-window) atomics, 4: no S scatter,
+// 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no MFMA, 64: no grad_value rounds at all.
 #ifndef BT_ABL
 #define BT_ABL 0
 #endif
@@ -34,15 +40,19 @@ namespace vllm {
 namespace {
 
 #ifdef BT_PROF
-__device__ unsigned long long g_bt_prof[16];   // phase clock of the diagnostics build (tools/msda_bwd_ablate.sh): ticks of wave 0 of every block
+__device__ unsigned long long g_bm_prof[16];   // phase clock of the diagnostics build (tools/msda_bwd_ablate.sh): ticks of wave 0 of every block
 #endif
 
 constexpr int BT_THREADS = 256;
 constexpr int BT_QPP = BT_THREADS / 8;   // 32 queries per pass (8 lanes x 4 channels = D 32)
 constexpr int BT_MAXL = 8;
-constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP, BT_WIN = 360;   // 360-pixel windows: 3 blocks per CU (see msda_tiled4_launch)
-constexpr size_t BT_LDS_WIN = (size_t)BT_WIN * 128, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
+constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
+constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
+constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in floats (odd: the scatter's banks spread)
+constexpr int BT_MAXWIN = 1024;           // larger windows: direct atomics
+constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
 constexpr size_t BT_LDS = BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 template <int K> __device__ __forceinline__ float qbc(float x)   // value of lane K of this lane's quad
 {
@@ -50,14 +60,14 @@ template <int K> __device__ __forceinline__ float qbc(float x)   // value of lan
 }
 template <int K> __device__ __forceinline__ int qbc(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
+__global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out, int B, int S, int M,
     int L, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attw)
 {
     constexpr int D = 32, PT = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *gwin = reinterpret_cast<float *>(smem);                                 // [<= 560 pixels][32] grad_value window
+    float *st = reinterpret_cast<float *>(smem);                                   // S^T [128 queries][BT_RP]: weight of query q on window pixel p of this round
     float2_t *s_loc = reinterpret_cast<float2_t *>(smem + BT_LDS_WIN);             // [128 queries][4 points]
     float *s_aw = reinterpret_cast<float *>(smem + BT_LDS_WIN + BT_LDS_LOC);       // [128 queries][4 points]
     __shared__ int s_H[BT_MAXL], s_W[BT_MAXL], s_q0[BT_MAXL], s_tc[BT_MAXL + 1];
@@ -66,6 +76,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
     __shared__ int s_geo_ok;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, hi = lane >> 5;
     const int sub = tid & 7;      // 4-channel chunk of this lane
     const int kpt = tid & 3;      // the sampling point this lane evaluates for its quad
     const int slot0 = tid >> 3;   // query slot inside a pass
@@ -128,6 +139,16 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             go[p] = *reinterpret_cast<const float4_t *>(grad_out + qidx[p] * D + sub * 4);
             if (!qok[p]) go[p] = (float4_t){0.f, 0.f, 0.f, 0.f};
         }
+        // B operand of the grad_value product: grad_out[query 2 s + hi][channel l31], s = 0 .. 63 (zero for slots outside the map);
+        // it stays in registers for all levels and rounds of the item
+        float gor[BT_NQ / 2];
+#pragma unroll
+        for (int s2 = 0; s2 < BT_NQ / 2; ++s2) {
+            bool ok;
+            const long pr = pair_of(2 * s2 + hi, ok);
+            const float v = grad_out[pr * D + l31];
+            gor[s2] = ok ? v : 0.f;
+        }
         bool lq_ok, aq_ok;
         const long lq_pair = pair_of(tid >> 1, lq_ok);
         const long aq_pair = pair_of(tid & (BT_NQ - 1), aq_ok);
@@ -187,14 +208,8 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             if (y1 < 0) continue;   // no accepted point at this level (block-uniform): all three gradients stay zero
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
-            const bool use_lds = npix <= BT_WIN;   // block-uniform
-
-            // ---- B: clear the accumulation window ----
-            if (use_lds && !(BT_ABL & 32)) {
-                for (int i = tid; i < npix * 8; i += BT_THREADS) reinterpret_cast<float4_t *>(gwin)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            }
-            __syncthreads();
-            BT_TICK(3)   // window barrier + clear + barrier
+            const bool use_win = npix <= BT_MAXWIN;   // block-uniform
+            BT_TICK(3)   // window barrier
 
             // ---- C: per (query, point): corner reads, the two per-point gradients, grad_value into the window ----
             float *gvl = grad_value + lbase + sub * 4;
@@ -217,9 +232,6 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
         const float4_t v2 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g2);                          \
         const float4_t v3 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g3);                          \
         const float4_t v4 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g4);                          \
-        /* window element offsets (LDS path) / global pointers (fallback path) of the four corners */                 \
-        const int e1 = ((h0 - y0) * ww + (x0 - x0w)) * 32 + sub * 4, e2 = ((h0 - y0) * ww + (x1 - x0w)) * 32 + sub * 4; \
-        const int e3 = ((h1 - y0) * ww + (x0 - x0w)) * 32 + sub * 4, e4 = ((h1 - y0) * ww + (x1 - x0w)) * 32 + sub * 4; \
         float *d1 = gvl + g1, *d2 = gvl + g2, *d3 = gvl + g3, *d4 = gvl + g4;                                          \
         float g_aw = 0.f, g_x = 0.f, g_y = 0.f;                                                                        \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                \
@@ -227,13 +239,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             const float a1 = k1 ? v1[c] : 0.f, a2 = k2 ? v2[c] : 0.f, a3 = k3 ? v3[c] : 0.f, a4 = k4 ? v4[c] : 0.f;    \
             const float ghw = -hw * a1 - lw * a2 + hw * a3 + lw * a4;                                                  \
             const float gww = -hh * a1 + hh * a2 - lh * a3 + lh * a4;                                                  \
-            if (use_lds) {                                                                                             \
-                if (BT_ABL & 4) { g_aw += w1 * tgv; } else                                                            \
-                if (k1) lds_add(e1 + c, w1 * tgv);                                                                     \
-                if (k2) lds_add(e2 + c, w2 * tgv);                                                                     \
-                if (k3) lds_add(e3 + c, w3 * tgv);                                                                     \
-                if (k4) lds_add(e4 + c, w4 * tgv);                                                                     \
-            } else if (!(BT_ABL & 2)) {                                                                              \
+            if (!use_win && !(BT_ABL & 2)) {                                                                         \
                 if (k1) unsafeAtomicAdd(d1 + c, w1 * tgv);                                                             \
                 if (k2) unsafeAtomicAdd(d2 + c, w2 * tgv);                                                             \
                 if (k3) unsafeAtomicAdd(d3 + c, w3 * tgv);                                                             \
@@ -254,33 +260,66 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
             grad_loc[2 * pi + 1] = g_y;                                                                                \
         }                                                                                                              \
     }
-            __attribute__((address_space(3))) float *gwin3 = (__attribute__((address_space(3))) float *)gwin;
-            auto lds_add = [&](int e, float v) {   // ds_add_f32 (no return value)
-                __hip_atomic_fetch_add(gwin3 + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
 #pragma unroll
             for (int p = 0; p < BT_NPASS; ++p) {
                 BT_POINT(0) BT_POINT(1) BT_POINT(2) BT_POINT(3)
             }
 #undef BT_POINT
-            BT_TICK(4)   // C: corner reads, gradients, LDS adds (or direct atomics)
-            if (!use_lds) continue;   // block-uniform
-            __syncthreads();
-            BT_TICK(5)   // barrier behind C
+            BT_TICK(4)   // C: corner reads, grad_loc / grad_attw (or direct atomics)
+            if (!use_win || (BT_ABL & 64)) continue;   // block-uniform
 
-            // ---- D: flush the window: one atomic per (pixel, channel), 128 contiguous bytes per pixel ----
-            float *gflush = grad_value + lbase;
+            // ---- D: grad_value of this level: rounds of 128 window pixels ----
+            __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
+            float *gflush = grad_value + lbase + l31;
             const unsigned ww_magic = (1u << 20) / (unsigned)ww + 1u;   // pix / ww exact for pix * ww < 2^20
-            for (int i = tid; i < ((BT_ABL & 64) ? 0 : npix * 8); i += BT_THREADS) {
-                const int pix = i >> 3, c4 = (i & 7) * 4;
-                const int wy = (int)(((unsigned)pix * ww_magic) >> 20), wx = pix - wy * ww;
-                const float4_t v = reinterpret_cast<const float4_t *>(gwin)[i];
-                float *g = gflush + ((long)(y0 + wy) * W + (x0w + wx)) * MD + c4;
+            for (int base = 0; base < npix; base += BT_R) {
+                __syncthreads();   // the previous round's (level's) reads of S^T are finished
+                for (int i = tid; i < (BT_NQ * BT_RP + 3) / 4; i += BT_THREADS) reinterpret_cast<float4_t *>(st)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                __syncthreads();
+                BT_TICK(5)   // clear + barriers
+                // (1) scatter: lanes 0-3 of every 8 own the four points of their query slot
+                if (!(tid & 4) && !(BT_ABL & 4)) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (v[c] != 0.f && !(BT_ABL & 1)) unsafeAtomicAdd(g + c, v[c]);
+                    for (int p = 0; p < BT_NPASS; ++p) {
+                        if (!okp[p]) continue;
+                        const int hl = hlo[p], wl = wlo[p];
+                        const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];
+                        const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
+                        const int q = p * BT_QPP + slot0;
+                        const int r0 = (hl - y0) * ww + (wl - x0w) - base;     // local index of corner (hl, wl); the others: +1, +ww, +ww+1
+                        const int i1 = r0, i2 = r0 + 1, i3 = r0 + ww, i4 = r0 + ww + 1;
+                        if (u0 && c0 && (unsigned)i1 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i1, (hh * hw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (u0 && c1 && (unsigned)i2 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i2, (hh * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (u1 && c0 && (unsigned)i3 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i3, (lh * hw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (u1 && c1 && (unsigned)i4 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i4, (lh * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                __syncthreads();
+                BT_TICK(6)   // scatter + barrier
+                // (2) this wave's 32-pixel chunk x grad_out on the matrix cores, (3) atomics straight from the accumulator layout
+                const int p0 = base + wave * 32;
+                if (p0 < npix) {   // (wave-uniform)
+                    f32x16_t acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    const float *ap = st + hi * BT_RP + wave * 32 + l31;
+                    if (!(BT_ABL & 32)) {
+#pragma unroll
+                        for (int s2 = 0; s2 < BT_NQ / 2; ++s2)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * BT_RP], gor[s2], acc, 0, 0, 0);
+                    }
+                    // accumulator register r: pixel (r & 3) + 8 (r >> 2) + 4 hi of the chunk, channel l31
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pix = p0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int wy = (int)(((unsigned)pix * ww_magic) >> 20), wx = pix - wy * ww;
+                        if (pix < npix && acc[r] != 0.f && !(BT_ABL & 1))
+                            unsafeAtomicAdd(gflush + ((long)(y0 + wy) * W + (x0w + wx)) * MD, acc[r]);
+                    }
+                }
+                BT_TICK(7)   // MFMA + flush
             }
-            BT_TICK(6)   // D: flush
 #ifdef BT_PROF
             pacc[8] += 1; pacc[9] += (unsigned)npix;
 #endif
@@ -288,21 +327,15 @@ __global__ __launch_bounds__(BT_THREADS, 3) void msda_bwd_tiled_kernel(
     }
 #ifdef BT_PROF
     if (tid == 0)
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_bt_prof[i], (unsigned long long)pacc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_bm_prof[i], (unsigned long long)pacc[i]);
 #endif
 }
 
 }  // namespace
 
-bool msda_bwd_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *grad_out, const void *loc)
-{
-    return msda_tiled_enabled() && D == 32 && P == 4 && L <= BT_MAXL && Lq == S && Lq >= 4096 && aligned16(value) &&
-           aligned16(grad_out) && (reinterpret_cast<uintptr_t>(loc) & 15u) == 0;
-}
-
-int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
-                          hipStream_t st)
+int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                         const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
+                         hipStream_t st)
 {
     static int cus = 0;
     if (cus == 0) {
@@ -313,13 +346,13 @@ int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64
     }
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BT_LDS);
     }
-    const int grid = (cus / 8) * 8 * 3;   // persistent: 3 blocks per CU
-    VLLM_LAUNCH(msda_bwd_tiled_kernel, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
+    const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
+    VLLM_LAUNCH(msda_bwd_mfma_kernel, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
                 Lq, gv, gl, gw);
-    VLLM_CHECK_LAUNCH("msda_bwd_tiled_kernel");
+    VLLM_CHECK_LAUNCH("msda_bwd_mfma_kernel");
     return VLLM_OK;
 }
 
@@ -327,18 +360,17 @@ int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64
 extern "C" int bt_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                           const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw, void *stream)
 {
-    return msda_bwd_tiled_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
+    return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
 }
 void set_error(const char *, ...) {}
-int msda_tiled_enabled() { return 1; }
 #ifdef BT_PROF
 extern "C" int bt_abl_prof(long *out)
 {
     unsigned long long h[16];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bt_prof), sizeof(h)) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bm_prof), sizeof(h)) != hipSuccess) return -1;
     for (int i = 0; i < 16; ++i) out[i] = (long)h[i];
     const unsigned long long z[16] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bm_prof), z, sizeof(z));
     return 0;
 }
 #endif
