@@ -362,15 +362,22 @@ def test_backward_f32_vectorised_vs_oracle(D, M, P):
     assert np.abs(rv32 - rv).max() <= 1e-3 * (1 + np.abs(rv).max())   # (fp32 oracle vs fp64 oracle: sanity)
 
 
+@pytest.mark.parametrize("spread", ["near", "medium", "far"])
 @pytest.mark.parametrize("shapes,B,M", [([(72, 64), (36, 32), (18, 16), (9, 8)], 2, 8), ([(65, 67), (33, 34)], 1, 3)])
-def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M):
-    """Encoder self-attention shape (Lq = S >= 4096, D 32, P 4): the LDS-tiled backward (window accumulation + flush), its
-    out-of-window fallback (far offsets), rejected / non-finite points, and the plain atomic kernel agree with the oracle."""
+def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M, spread):
+    """Encoder self-attention shape (Lq = S >= 4096, D 32, P 4): the windowed backward (msda_bwd_mfma.hip: the value window
+    staged in LDS, grad_value as S^T x grad_out on the matrix cores) -- windows of one round (near), of several 128-pixel rounds
+    and beyond the staging limit (medium), and the global-atomic fallback for windows over 1024 pixels (far) --, rejected /
+    non-finite points, and the plain atomic kernel agree with the oracle."""
     from visionllm_amd import _lib
     g = make_inputs(B, M, 32, shapes, 4, mode="encoder_like", seed=len(shapes) + M)
     loc = g["loc"].copy()
     flat = loc.reshape(-1, 2)
-    flat[7::41] += 0.37            # far offsets: some (tile, level) windows exceed the LDS budget -> global-atomic fallback
+    if spread == "far":
+        flat[7::41] += 0.37        # far offsets: some (tile, level) windows exceed 1024 pixels -> global-atomic fallback
+    elif spread == "medium":
+        rng0 = np.random.default_rng(5)
+        flat[2::3] += (rng0.standard_normal(flat[2::3].shape) * 0.06).astype(np.float32)   # windows of a few hundred pixels
     flat[3::29] = 1.7              # rejected points
     flat[5::97] = np.nan
     Lq = loc.shape[1]
@@ -397,9 +404,12 @@ def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M):
             np.testing.assert_allclose(res[mode][2][sel], rw[sel], rtol=1e-4, atol=1e-4)
             np.testing.assert_allclose(res[mode][1][sel], rl[sel], rtol=2e-3, atol=2e-3)
             assert (np.abs(res[mode][0] - rv32) <= 2.0 ** -18 * mag + 1e-7).all(), mode   # per element vs the fp32 oracle
-        # the two kernels evaluate every point with the same instruction sequence: per-point gradients are identical,
-        # grad_value differs only by the order of the atomic sums
-        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][1], res[0][1])
+        # the windowed kernel sums over the channels first (four dot products per point, then the bilinear weights), the plain one
+        # weights per channel and sums then: the per-point gradients agree to fp32 rounding of sums of ~32 terms, grad_value differs
+        # only by the order of its sums
+        for i in (1, 2):
+            scale = np.abs(res[0][i]).max() + 1e-12
+            np.testing.assert_allclose(res[1][i], res[0][i], rtol=1e-4, atol=2e-6 * scale)
         np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4, atol=1e-4)
     finally:
         _lib.set_option("msda_tiled", old)

@@ -50,6 +50,7 @@ constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / B
 constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
 constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in floats (odd: the scatter's banks spread)
 constexpr int BT_MAXWIN = 1024;           // larger windows: direct atomics
+constexpr int BT_STAGE = 512;             // windows up to this many pixels are staged in LDS (in the S^T buffer, free during phase C) for the corner reads
 constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
 constexpr size_t BT_LDS = BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -59,6 +60,13 @@ template <int K> __device__ __forceinline__ float qbc(float x)   // value of lan
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), K * 0x55, 0xf, 0xf, false));
 }
 template <int K> __device__ __forceinline__ int qbc(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dpp_add(float x)   // x + (x of the lane CTRL selects)
+{
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 8 lanes {8 n .. 8 n + 7}; valid in lane 8 n (quad butterfly: quad_perm [1,0,3,2], [2,3,0,1]; then row_shl:4 brings
+// the upper quad's sum down: lane i reads lane i + 4)
+__device__ __forceinline__ float sum8(float x) { return dpp_add<0x104>(dpp_add<0x4e>(dpp_add<0xb1>(x))); }
 
 __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
@@ -209,7 +217,23 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
+            const bool use_stage = npix <= BT_STAGE;  // block-uniform
             BT_TICK(3)   // window barrier
+            // ---- B: the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave instruction, LDS-DMA.  The
+            //      window only holds pixels of the map (its box comes from clamped corners), so there is nothing to zero-fill.
+            if (use_stage && !(BT_ABL & 8)) {
+                const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
+                for (int p0 = wave * 8; p0 < npix; p0 += 32) {
+                    const int pix = min(p0 + (lane >> 3), npix - 1);
+                    const int wy = (int)(((unsigned)pix * ww_m) >> 20), wx = pix - wy * ww;
+                    const float *src = value + lbase + ((long)(y0 + wy) * W + (x0w + wx)) * MD + (lane & 7) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(smem + p0 * 128), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            BT_TICK(8)   // B: window staging
 
             // ---- C: per (query, point): corner reads, the two per-point gradients, grad_value into the window ----
             float *gvl = grad_value + lbase + sub * 4;
@@ -260,10 +284,50 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             grad_loc[2 * pi + 1] = g_y;                                                                                \
         }                                                                                                              \
     }
+            // Staged window (the common case): the per-point gradients only need the four dot products  d_i = <grad_out, corner i>
+            // over the 32 channels:  grad_attw = sum_i w_i d_i,  grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),
+            // grad_y = H aw (hw (d3 - d1) + lw (d4 - d2))  -- 16 multiply-adds per lane and point instead of ~100, the sums over the
+            // 8 lanes of a query by DPP adds (quad butterfly, then the upper quad onto the lower one: lane 0 of the 8 owns the result).
+#define BT_LEAN_POINT(K)                                                                                               \
+    {                                                                                                                  \
+        const int hl = qbc<K>(hlo[p]), wl = qbc<K>(wlo[p]);                                                            \
+        const bool pok = qbc<K>(okp[p]) != 0;                                                                          \
+        const float bh = qbc<K>(him[p]), bw = qbc<K>(wim[p]), aw = qbc<K>(awp[p]);                                     \
+        const float lh = bh - (float)hl, lw = bw - (float)wl;                                                          \
+        const float hh = 1.f - lh, hw = 1.f - lw;                                                                      \
+        const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;                             \
+        const bool k1 = pok && u0 && c0, k2 = pok && u0 && c1, k3 = pok && u1 && c0, k4 = pok && u1 && c1;            \
+        const int r0 = ((hl - y0) * ww + (wl - x0w)) * 128 + sub * 16, rw = ww * 128;                                  \
+        const float4_t v1 = *reinterpret_cast<const float4_t *>(smem + (k1 ? r0 : 0));                                 \
+        const float4_t v2 = *reinterpret_cast<const float4_t *>(smem + (k2 ? r0 + 128 : 0));                           \
+        const float4_t v3 = *reinterpret_cast<const float4_t *>(smem + (k3 ? r0 + rw : 0));                            \
+        const float4_t v4 = *reinterpret_cast<const float4_t *>(smem + (k4 ? r0 + rw + 128 : 0));                      \
+        const float4_t g = go[p];                                                                                      \
+        float d1 = g[0] * v1[0] + g[1] * v1[1] + g[2] * v1[2] + g[3] * v1[3];                                          \
+        float d2 = g[0] * v2[0] + g[1] * v2[1] + g[2] * v2[2] + g[3] * v2[3];                                          \
+        float d3 = g[0] * v3[0] + g[1] * v3[1] + g[2] * v3[2] + g[3] * v3[3];                                          \
+        float d4 = g[0] * v4[0] + g[1] * v4[1] + g[2] * v4[2] + g[3] * v4[3];                                          \
+        d1 = k1 ? d1 : 0.f; d2 = k2 ? d2 : 0.f; d3 = k3 ? d3 : 0.f; d4 = k4 ? d4 : 0.f;                                \
+        d1 = sum8(d1); d2 = sum8(d2); d3 = sum8(d3); d4 = sum8(d4);                                                    \
+        if (sub == 0 && pok && !(BT_ABL & 16)) {   /* rejected points keep the caller's zero fill */                   \
+            const long pi = (qidx[p] * L + l) * PT + K;                                                                \
+            grad_attw[pi] = ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4);                     \
+            grad_loc[2 * pi] = (float)W * aw * (hh * (d2 - d1) + lh * (d4 - d3));                                      \
+            grad_loc[2 * pi + 1] = (float)H * aw * (hw * (d3 - d1) + lw * (d4 - d2));                                  \
+        }                                                                                                              \
+    }
+            if (use_stage) {
 #pragma unroll
-            for (int p = 0; p < BT_NPASS; ++p) {
-                BT_POINT(0) BT_POINT(1) BT_POINT(2) BT_POINT(3)
+                for (int p = 0; p < BT_NPASS; ++p) {
+                    BT_LEAN_POINT(0) BT_LEAN_POINT(1) BT_LEAN_POINT(2) BT_LEAN_POINT(3)
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) {
+                    BT_POINT(0) BT_POINT(1) BT_POINT(2) BT_POINT(3)
+                }
             }
+#undef BT_LEAN_POINT
 #undef BT_POINT
             BT_TICK(4)   // C: corner reads, grad_loc / grad_attw (or direct atomics)
             if (!use_win || (BT_ABL & 64)) continue;   // block-uniform
@@ -321,7 +385,7 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
                 BT_TICK(7)   // MFMA + flush
             }
 #ifdef BT_PROF
-            pacc[8] += 1; pacc[9] += (unsigned)npix;
+            pacc[9] += 1; pacc[10] += (unsigned)npix;
 #endif
         }
     }
