@@ -27,12 +27,13 @@ print(f"kernel {e0.elapsed_time(e1):.3f} ms")
 L.bt_abl_prof(buf)
 if "mfma" in name:
     names = ["item set-up (+ grad_out operand)", "level hand-over (2 barriers)", "A points + wave reduction", "window barrier", "C corner reads / grad_loc / grad_attw",
-             "D clear S^T + barriers", "D scatter + barrier", "D MFMA + flush atomics", "B value window -> LDS (DMA + wait + barrier)"]
+             "D wipe staged window + barriers", "D scatter + barrier", "D MFMA + flush atomics", "B value window -> LDS (DMA + wait + barrier)", "-", "-", "D barrier + un-scatter"]
 else:
     names = ["item set-up", "level hand-over (2 barriers)", "A points + wave reduction", "window barrier + clear + barrier", "C corner reads / gradients / LDS adds",
              "barrier behind C", "D flush (global atomics)"]
 tot = sum(buf[i] for i in range(len(names)))
 for i, n in enumerate(names):
-    print(f"{n:40s} {buf[i]:14d} {100.0 * buf[i] / tot:6.1f} %")
+    if n != "-": print(f"{n:40s} {buf[i]:14d} {100.0 * buf[i] / tot:6.1f} %")
 c0, c1 = (9, 10) if "mfma" in name else (8, 9)
+if "mfma" in name: tot -= buf[9] + buf[10]
 print(f"level passes {buf[c0]}  mean window {buf[c1] / max(buf[c0], 1):.0f} px  ticks per level pass {tot / max(buf[c0], 1):.0f}")

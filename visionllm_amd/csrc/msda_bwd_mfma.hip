@@ -114,6 +114,7 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
     const long ipx = (n_items + 7) >> 3;
     const int blocks_per_xcd = gridDim.x >> 3;
 
+    for (int i = tid; i < (BT_NQ * BT_RP + 3) / 4; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     for (long j = blockIdx.x >> 3; j < ipx; j += blocks_per_xcd) {
         const long item = (long)xcd * ipx + j;
         if (item >= n_items) break;
@@ -336,27 +337,36 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
             float *gflush = grad_value + lbase + l31;
             const unsigned ww_magic = (1u << 20) / (unsigned)ww + 1u;   // pix / ww exact for pix * ww < 2^20
-            for (int base = 0; base < npix; base += BT_R) {
-                __syncthreads();   // the previous round's (level's) reads of S^T are finished
-                for (int i = tid; i < (BT_NQ * BT_RP + 3) / 4; i += BT_THREADS) reinterpret_cast<float4_t *>(st)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            // S^T is zero whenever a round starts: zeroed once per kernel, the staged value window is wiped here, and every round
+            // takes its own entries back out after the product ("un-scatter": 16 stores per lane instead of a 66 KB clear).
+            __syncthreads();   // phase C's reads of the staged window are finished
+            if (use_stage) {
+                const int nz = ((npix + 7) & ~7) * 8;   // float4 elements the staging wrote
+                for (int i = tid; i < nz; i += BT_THREADS) reinterpret_cast<float4_t *>(st)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
                 __syncthreads();
-                BT_TICK(5)   // clear + barriers
-                // (1) scatter: lanes 0-3 of every 8 own the four points of their query slot
-                if (!(tid & 4) && !(BT_ABL & 4)) {
+            }
+            BT_TICK(5)   // wipe + barriers
+            for (int base = 0; base < npix; base += BT_R) {
+                // (1) scatter: lane (query slot, sub) owns point sub & 3 of its slot's queries (both lanes sub and sub + 4 evaluated it in
+                // phase A) and two of its four corners -- the upper pair for sub < 4, the lower pair otherwise: every lane of the wave
+                // has work, 8 LDS float atomics per lane and round.  (An LDS float atomic instruction costs ~100 cycles of the wave's
+                // time whatever its lane count; ordered plain read-add-write turns of the four points were measured no faster.)
+                // Corners outside the map or the round are skipped (the un-scatter sends their zero to the row's pad column).
+                int sidx[BT_NPASS][2];
 #pragma unroll
-                    for (int p = 0; p < BT_NPASS; ++p) {
-                        if (!okp[p]) continue;
-                        const int hl = hlo[p], wl = wlo[p];
-                        const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl;
-                        const float hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];
-                        const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
-                        const int q = p * BT_QPP + slot0;
-                        const int r0 = (hl - y0) * ww + (wl - x0w) - base;     // local index of corner (hl, wl); the others: +1, +ww, +ww+1
-                        const int i1 = r0, i2 = r0 + 1, i3 = r0 + ww, i4 = r0 + ww + 1;
-                        if (u0 && c0 && (unsigned)i1 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i1, (hh * hw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (u0 && c1 && (unsigned)i2 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i2, (hh * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (u1 && c0 && (unsigned)i3 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i3, (lh * hw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (u1 && c1 && (unsigned)i4 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + q * BT_RP + i4, (lh * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int p = 0; p < BT_NPASS; ++p) {
+                    const int hl = hlo[p] + (sub >> 2), wl = wlo[p];          // this lane's corner row
+                    const float lh = him[p] - (float)hlo[p], lw = wim[p] - (float)wl;
+                    const float wy_ = (sub >> 2) ? lh : 1.f - lh, aw = awp[p];
+                    const bool ur = okp[p] && hl >= 0 && hl <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
+                    const int row = (p * BT_QPP + slot0) * BT_RP;
+                    const int i1 = (hl - y0) * ww + (wl - x0w) - base, i2 = i1 + 1;
+                    sidx[p][0] = row + ((ur && c0 && (unsigned)i1 < (unsigned)BT_R) ? i1 : BT_R);
+                    sidx[p][1] = row + ((ur && c1 && (unsigned)i2 < (unsigned)BT_R) ? i2 : BT_R);
+                    // (predicated, not redirected: atomics of several lanes on one pad word would serialise)
+                    if (!(BT_ABL & 4)) {
+                        if (sidx[p][0] != row + BT_R) __hip_atomic_fetch_add(st3 + sidx[p][0], (wy_ * (1.f - lw)) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (sidx[p][1] != row + BT_R) __hip_atomic_fetch_add(st3 + sidx[p][1], (wy_ * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 __syncthreads();
@@ -383,6 +393,10 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
                     }
                 }
                 BT_TICK(7)   // MFMA + flush
+                __syncthreads();   // every wave has read S^T
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) { st[sidx[p][0]] = 0.f; st[sidx[p][1]] = 0.f; }
+                BT_TICK(11)   // barrier + un-scatter
             }
 #ifdef BT_PROF
             pacc[9] += 1; pacc[10] += (unsigned)npix;
