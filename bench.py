@@ -198,6 +198,22 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         del tn
     except Exception as e:   # measurement extra: never fail the bench line for it
         out["msda_nonpyramid"] = {"error": repr(e)}
+    # MSDA backward at the encoder shape (the det / pose heads are trained): not part of the forward step, isolated.
+    # Algorithmic bytes: everything the forward reads + grad_out, and the three gradients written once (grad_value is accumulated
+    # with atomics; its zero fill is the caller's and not counted).
+    try:
+        t = msda_in["enc"]
+        go = torch.randn(t["loc"].shape[0], t["loc"].shape[1], t["value"].shape[2] * t["value"].shape[3], device=dev)
+        f = lambda: A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, 3)
+        ab = 2 * msda_bytes(t)
+        out["msda_bwd"] = entry("-", "msda_bwd_mfma_kernel + zero fill of the gradients (fp32, D32, encoder shape Lq=S=37485, B=8; grad_value = S^T x grad_out on "
+                                "v_mfma_f32_32x32x2_f32)", "hbm", ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
+                                note="not part of the step (training only); time includes the torch.zeros of the three gradients")
+        del go
+    except Exception as e:   # measurement extra: never fail the bench line for it
+        out["msda_bwd"] = {"error": repr(e)}
     # attention: MFMA bound, flops = 4*H*S^2*d per tile
     qkv = torch.randn(n_tiles, S, 3, H, D, device=dev).to(torch.bfloat16)
     ao = torch.empty(n_tiles, S, H, D, dtype=torch.bfloat16, device=dev)
