@@ -1,29 +1,27 @@
-# One GPU-box pass that regenerates what profiles/r02_* quotes (round 2): full -m gpu suite, smoke, the bench line of both
-# workloads, rocprofv3 kernel stats of the bench (csv), FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only),
-# the micro-benchmarks and phase clocks.  The individual passes of the round, as they were run, are in tools/gpu_passes/.
-#   gpurun --timeout 2400 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r02z_* into profiles/ under their r02_ names
+# One GPU-box pass that regenerates what profiles/r03_* quote at the end of round 3: full -m gpu suite, smoke, the default bench
+# line (ViT-L + the internvit6b key), rocprofv3 kernel stats of both workloads (csv), FETCH_SIZE / WRITE_SIZE PMC passes (separate
+# runs, kernel-trace only), the MSDA backward phase clocks.  The individual passes of the round, as they were run, are in
+# tools/gpu_passes/ (round 2's version of this script: git history).
+#   gpurun --timeout 2700 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r03z/* into profiles/ under their r03_ names
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1
-timeout 600 python bench.py > gpurun_out/r02z_bench_line.json 2> gpurun_out/r02z_bench_err.txt; tail -c 400 gpurun_out/r02z_bench_line.json
-timeout 900 python bench.py --workload internvit6b --steps 5 --warmup 2 > gpurun_out/r02z_bench_line_internvit6b.json 2>> gpurun_out/r02z_bench_err.txt
-rm -rf gpurun_out/r02z_prof gpurun_out/r02z_fetch gpurun_out/r02z_write
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02z_prof -o bench -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r02z_bench_prof_line.json 2> /dev/null
-f=$(find gpurun_out/r02z_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -40 "$f" > gpurun_out/r02z_bench_kernel_stats.csv
-find gpurun_out/r02z_prof -name '*kernel_trace*' -delete
-(cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r02z_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
- timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r02z_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
-python tools/collect_pmc.py gpurun_out/r02z_fetch gpurun_out/r02z_write gpurun_out/r02z_pmc_traffic.json vitl | head -30
-find gpurun_out/r02z_fetch gpurun_out/r02z_write -name '*.csv' -size +2M -delete
-python tools/bench_msda.py --iters 20 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_msda_microbench.txt
-T6_PROF_MODE=16 python tools/prof_msda6.py 2>&1 | tail -22 | tee gpurun_out/r02z_msda7_phases.txt
-python tools/bench_msda_layer.py 2>&1 | tail -2 | tee gpurun_out/r02z_msda_layer.txt
-python tools/bench_attn.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_attn.txt
-python tools/attn_zero_data.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_attn_zero_data.txt
-python tools/bench_dcnv3.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_dcnv3_tiled.txt
-python tools/prof_dcnv3.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_dcnv3_phases.txt
-python tools/prof_gemm256.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_gemm256_phases.txt
-python tools/trace_gemm256.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02z_gemm256_block_trace.txt
+O=gpurun_out/r03z
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1 | tee $O/smoke.txt
+timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_err.txt; tail -c 300 $O/bench_line.json
+rm -rf $O/prof_v $O/prof_i $O/fetch $O/write
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_v -o bench -- python bench.py --workload vitl --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_prof_line_vitl.json 2> /dev/null
+f=$(find $O/prof_v -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -40 "$f" > $O/bench_kernel_stats_vitl.csv
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_i -o bench -- python bench.py --workload internvit6b --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_prof_line_internvit6b.json 2> /dev/null
+f=$(find $O/prof_i -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -40 "$f" > $O/bench_kernel_stats_internvit6b.csv
+find $O -name '*kernel_trace*' -delete
+find $O/prof_v $O/prof_i -type f -size +1M -delete
+(cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/fetch -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
+python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -30
+find $O/fetch $O/write -name '*.csv' -size +2M -delete
+python tools/msda_bwd_phases.py libmsdabwd_mfma_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_mfma_phases.txt
+python tools/msda_bwd_phases.py libmsdabwd_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_lds_phases.txt
