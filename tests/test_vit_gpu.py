@@ -552,6 +552,8 @@ def test_flash_attention_hook_and_rmsnorm_hook():
     close(out, _attn_ref(qkv.cpu(), 2, 64, 64 ** -0.5), 1e-2, "FlashAttention hook")
     with pytest.raises(NotImplementedError):
         FlashAttention()(qkv, causal=True)
+    with pytest.raises(NotImplementedError, match=r"flash_attention\.py:39-41"):   # fp16: accepted by the reference, named as not implemented here
+        FlashAttention()(qkv.to(torch.float16))
     n = InternRMSNorm(128, eps=1e-6).to(DEV).to(torch.bfloat16)
     x = bf(torch.randn(3, 5, 128, device=DEV))
     close(n(x), V.rms_norm(x.cpu(), n.weight.detach().cpu(), 1e-6), 8e-3, "InternRMSNorm hook")

@@ -22,8 +22,13 @@ class FlashAttention(nn.Module):
             raise NotImplementedError("native FlashAttention: only dense non-causal qkv[B,S,3,H,D] (the ViT tile case)")
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("native FlashAttention: attention dropout is not implemented (inference path)")
+        if qkv.dtype == torch.float16:
+            # the reference accepts fp16 and bf16 (flash_attention.py:39-41: `assert qkv.dtype in [torch.float16, torch.bfloat16]`);
+            # the native kernel computes in bf16 only -- the dtype the vision tower runs in (modeling_visionllmv2.py casts it to bf16)
+            raise NotImplementedError("native FlashAttention: fp16 qkv is accepted by the reference (flash_attention.py:39-41) but not "
+                                      "implemented here; the vision tower runs in bf16 -- cast qkv to torch.bfloat16")
         if qkv.dtype != torch.bfloat16 or not qkv.is_cuda or qkv.dim() != 5 or qkv.shape[2] != 3:
-            raise RuntimeError("native FlashAttention: qkv must be a bf16 CUDA tensor [B, S, 3, H, D]")
+            raise RuntimeError("native FlashAttention: qkv must be a bf16 CUDA tensor [B, S, 3, H, D] (flash_attention.py:39-41)")
         qkv = qkv.contiguous()
         B, S, _, H, D = qkv.shape
         out = torch.empty((B, S, H, D), dtype=qkv.dtype, device=qkv.device)
