@@ -247,8 +247,8 @@ int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, u
 /* The same GEMM with caller-provided scratch for the stream-K tail of the 8-phase schedule: when the tiles of a GEMM do not
  * fill a whole number of rounds on the device's CUs, the K iterations of the last round's tiles are spread evenly over all CUs
  * (fp32 partial tiles meet in `scratch`, summed in a fixed order: results are run-to-run identical).  `scratch` is
- * vllm_gemm_scratch_bytes() bytes, 16-byte aligned, its first 4096 bytes ZERO before the first call (the kernel leaves them
- * zero); calls sharing a scratch must be ordered on one stream.  NULL scratch = vllm_gemm_bf16.  vllm_vit_forward /
+ * vllm_gemm_scratch_bytes() bytes, 16-byte aligned; the call resets its first 4096 bytes (flags) with a memset node in front of
+ * the kernel; calls sharing a scratch must be ordered on one stream.  NULL scratch = vllm_gemm_bf16.  vllm_vit_forward /
  * vllm_bridge_forward reserve theirs inside their workspace. */
 long vllm_gemm_scratch_bytes(void);
 long vllm_gemm_sk_launches(void);   /* GEMM launches of this process that took the stream-K tail (tests / tuning) */

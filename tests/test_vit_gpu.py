@@ -177,7 +177,7 @@ os.environ.setdefault("VLLM_GEMM_SK_FIX", "0")   # tests: the stream-K tail wher
 
 def _sk_scratch():
     n = _lib.lib().vllm_gemm_scratch_bytes()
-    return torch.zeros(n, dtype=torch.uint8, device=DEV), n
+    return torch.full((n,), 0xFF, dtype=torch.uint8, device=DEV), n   # (poisoned: the entry resets the flags itself)
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024),      # 64 tiles on 256 CUs: every tile is shared by four blocks

@@ -331,6 +331,9 @@ extern "C" int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uin
     VLLM_REQUIRE(!scratch || (scratch_bytes >= SK_FLAG_BYTES + SK_SLOT_BYTES && aligned16(scratch)), "vllm_gemm_bf16_sk: scratch too small or misaligned");
     GemmArgs a;
     gemm_set_scratch(a, scratch, scratch_bytes);
+    // the flags are reset in front of every call of THIS entry (a memset node of 4 KB: a call that died half way, or a caller that
+    // never zeroed its scratch, must not hand a stale "slot ready" to the next one); the orchestrators reset theirs once per forward
+    if (scratch) VLLM_REQUIRE(hipMemsetAsync(scratch, 0, SK_FLAG_BYTES, (hipStream_t)stream) == hipSuccess, "vllm_gemm_bf16_sk: flag reset failed");
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;
