@@ -192,9 +192,12 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         sec = event_time(f, iters)
         tn["values"] = [tn["value"]]
         ab = msda_bytes(tn)
-        out["msda_nonpyramid"] = entry("-", "msda_fwd_tiled4_kernel (any-geometry kernel: levels 100x167 / 50x84 / 25x42 / 13x21, B=8, Lq=S)", "hbm",
+        geo_n = A.known_geometry(tn["shapes"], tn["loc"].shape[1])
+        kern_n = ("msda_fwd_tiled7_kernel (pyramid items on NESTED maps: ceil-divided levels" if geo_n == A.GEO_PYRAMID
+                  else "msda_fwd_tiled4_kernel (any-geometry kernel: levels")
+        out["msda_nonpyramid"] = entry("-", kern_n + " 100x167 / 50x84 / 25x42 / 13x21, B=8, Lq=S)", "hbm",
                                        ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
-                                       note="not part of the step: the pyramid-item kernel needs exact 2x levels; this is what other geometries get")
+                                       note="not part of the step: the level maps of an 800 x 1333 detection input (not exact halves)")
         del tn
     except Exception as e:   # measurement extra: never fail the bench line for it
         out["msda_nonpyramid"] = {"error": repr(e)}

@@ -143,6 +143,10 @@ PYRAMIDS = {
     "L3": [(64, 80), (32, 40), (16, 20)],
     "L2_odd_rows": [(76, 64), (38, 32)],                              # 76 / 8 = 9.5 tile rows
     "L1": [(72, 64)],
+    # nested maps that are NOT exact halves (the ceil- / floor-divided levels of a detection backbone): same kernel, masked cells
+    "L4_ceil_divided": [(50, 83), (25, 42), (13, 21), (7, 11)],
+    "L4_floor_divided": [(51, 83), (25, 41), (12, 20), (6, 10)],
+    "L3_mixed_rounding": [(45, 70), (23, 35), (11, 18)],
 }
 
 
@@ -812,7 +816,7 @@ def test_fused_layer_module_flavours_and_fallbacks():
 
 # ---------------------------------------------------------------------------------------------------------
 # round 3: host-known level geometry (one kernel launch instead of two) and inference-mode tensors
-@pytest.mark.parametrize("shapes", [[(72, 64), (36, 32), (18, 16), (9, 8)], [(61, 83), (31, 42), (9, 5)]])
+@pytest.mark.parametrize("shapes", [[(72, 64), (36, 32), (18, 16), (9, 8)], [(50, 83), (25, 42), (13, 21), (7, 11)], [(61, 83), (31, 42), (9, 5)]])
 def test_geometry_hint_changes_launches_not_results(shapes):
     """vllm_msda_forward_f32_geo: UNKNOWN (both kernels enqueued, the device picks), the hint a module's shape check leaves
     behind (exactly one kernel) and the opposite extreme (GENERAL forced for a pyramid) give the same tensor."""
@@ -824,7 +828,8 @@ def test_geometry_hint_changes_launches_not_results(shapes):
     assert A.known_geometry(ss, Lq) == A.GEO_UNKNOWN          # nobody has looked at this tensor object yet
     unknown = A.ms_deform_attn_forward(v, ss, lsi, loc, w, 64)
     geo = A.remember_geometry(ss)
-    is_pyr = all((h << l) == shapes[0][0] and (ww << l) == shapes[0][1] for l, (h, ww) in enumerate(shapes))
+    is_pyr = A.nested_maps(shapes)   # exact halves or ceil- / floor-divided levels; (31, 42) -> (9, 5) is neither
+    assert is_pyr == (shapes[-1] != (9, 5))
     assert geo == (A.GEO_PYRAMID if is_pyr else A.GEO_GENERAL) and A.known_geometry(ss, Lq) == geo
     assert A.known_geometry(ss, Lq - 1) == (A.GEO_GENERAL if is_pyr else geo)   # a pyramid only for the encoder's queries
     hinted = A.ms_deform_attn_forward(v, ss, lsi, loc, w, 64)

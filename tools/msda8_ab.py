@@ -32,8 +32,8 @@ buf = (ctypes.c_long * 16)()
 lib.vllm_debug_counters(buf, 16)
 run(); torch.cuda.synchronize()
 n = lib.vllm_debug_counters(buf, 16)
-names = ["barrier+loop", "P1 points+boxes", "P2 layout+offsets", "P2 dma issue", "P2 dma wait", "G0 head", "G0 gather", "G1 gather+prefetch",
-         "-", "-", "-", "-", "cold levels", "-", "items", "-"]
+names = ["barrier+loop", "P1 points+boxes", "P2 layout+offsets", "P2 dma issue", "P2 dma wait", "G head", "G0 gather", "G1 gather+prefetch",
+         "P team meeting point", "G pass 0 late level + store", "-", "-", "cold levels", "late levels", "items", "-"]
 tot = sum(buf[i] for i in range(12))
 for i in range(16):
-    if names[i] != "-": print(f"{names[i]:22s} {buf[i]:14d} {100.0 * buf[i] / max(tot, 1):6.1f} %" if i < 12 else f"{names[i]:22s} {buf[i]:14d}")
+    if names[i] != "-": print(f"{names[i]:28s} {buf[i]:14d} {100.0 * buf[i] / max(tot, 1):6.1f} %" if i < 12 else f"{names[i]:28s} {buf[i]:14d}")

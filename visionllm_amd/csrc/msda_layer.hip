@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 {
     // shapes != null: the operator already wrote bf16 for a pyramid geometry (msda_forward_f32_out16) -- nothing to do then.
     // Grid-stride over a fixed grid, so that this "nothing" costs a couple of microseconds instead of 75 k empty blocks.
-    if (shapes && geometry_is_pyramid(shapes, L, Lq)) return;
+    if (shapes && geometry_is_nested(shapes, L, Lq)) return;   // (the predicate of the generation-7 kernel, which then wrote bf16 itself)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4_t v = reinterpret_cast<const float4_t *>(src)[i];
         uint2_t o;

@@ -68,4 +68,25 @@ __device__ __forceinline__ bool geometry_is_pyramid(const int64_t *shapes, int L
     return ok && cum == Lq;
 }
 
+// The generation-7 kernel only needs NESTED maps: level l is the previous one halved, rounded either way (what strided
+// convolutions / ceil-mode poolings give a detection backbone: 100 x 167 -> 50 x 84 -> 25 x 42 -> 13 x 21), every query of level
+// l then belongs to exactly one 8 x 16 item of level 0 (row y >> (3 - l), column x >> (4 - l)) and every level-l query of an
+// item exists or is masked.  Exact 2x pyramids are the special case without masked cells.
+__device__ __forceinline__ bool geometry_is_nested(const int64_t *shapes, int L, long Lq)
+{
+    if (L < 1 || L > 4) return false;
+    int Hp = (int)shapes[0], Wp = (int)shapes[1];
+    bool ok = Hp > 0 && Wp > 0;
+    const int nty = (Hp + 7) >> 3, ntx = (Wp + 15) >> 4;
+    long cum = (long)Hp * Wp;
+    for (int l = 1; l < L; ++l) {
+        const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+        ok = ok && Hl > 0 && Wl > 0 && Hl >= (Hp >> 1) && Hl <= ((Hp + 1) >> 1) && Wl >= (Wp >> 1) && Wl <= ((Wp + 1) >> 1) &&
+             Hl <= nty * (8 >> l) && Wl <= ntx * (16 >> l);
+        cum += (long)Hl * Wl;
+        Hp = Hl; Wp = Wl;
+    }
+    return ok && cum == Lq;
+}
+
 }  // namespace vllm

@@ -353,14 +353,18 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
     // geometry (VLLM_GEO_*): what the HOST knows about the level maps.  UNKNOWN: both kernels are enqueued and the device
     // picks (no host synchronisation; one ~5 us empty launch); PYRAMID / GENERAL: exactly one launch.
+    // (generation 8 -- an experiment on exact pyramids without the layer's bf16 output contract -- only for plain fp32 calls)
+    const bool gen8 = (mode == 18 || mode == 19) && !out16;
     if ((mode == 1 || mode == 15 || mode == 16 || mode == 18 || mode == 19) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
         geometry != VLLM_GEO_GENERAL) {
+        if (gen8) {   // its predicate is the exact pyramid, the host hint speaks of nested maps: always both launches
+            if (int e = msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 19, st, nullptr, 0)) return e;
+            return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
+        }
         if (out16 && wrote16) *wrote16 = 1; else out16 = nullptr;
-        if (mode >= 18) {
-            if (int e = msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 19, st, out16, geometry == VLLM_GEO_PYRAMID)) return e;
-        } else if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16, geometry == VLLM_GEO_PYRAMID)) return e;
+        if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16, geometry == VLLM_GEO_PYRAMID)) return e;
         if (geometry == VLLM_GEO_PYRAMID) return VLLM_OK;
-        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
+        return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 2, st);
     }
     if (mode >= 10 && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw)) {
         if (int e = msda_tiled6_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st)) return e;

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(NW * 64, NW * BPC / 4) void msda_fwd_tiled4_kernel(
     float *__restrict__ out, int skip_pyramid)
 {
     constexpr int D = 32, PT = 4;
-    if (skip_pyramid && geometry_is_pyramid(shapes, L, Lq)) return;   // served by the generation-6 kernel launched ahead of this one
+    // served by the kernel launched ahead of this one: 1 = an exact-pyramid kernel (generations 6 / 8), 2 = generation 7 (nested maps)
+    if (skip_pyramid == 1 && geometry_is_pyramid(shapes, L, Lq)) return;
+    if (skip_pyramid == 2 && geometry_is_nested(shapes, L, Lq)) return;
     constexpr int T4_THREADS = T4Shape<NW, TH>::THREADS, T4_QPP = T4Shape<NW, TH>::QPP, T4_NPASS = T4Shape<NW, TH>::NPASS;
     constexpr int NOWN = T4Shape<NW, TH>::NOWN;
     extern __shared__ __attribute__((aligned(16))) char smem[];

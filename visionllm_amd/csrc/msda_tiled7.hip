@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_box = reinterpret_cast<int *>(smem + (T6_ZPX + R + T6_SLACK) * 128);   // [3][4 levels][4]: min hl, min -hl, min wl, min -wl
 
-    if (!geometry_is_pyramid(shapes, L, Lq)) {
+    if (!geometry_is_nested(shapes, L, Lq)) {
         // hinted: the host said "pyramid" and launched no other kernel -- a stale hint must fail loudly, not leave `out` unwritten
         if (hinted) __builtin_trap();
         return;
@@ -72,7 +72,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     const int k = lane & 3;                       // the value level this lane owns
     const unsigned MD = (unsigned)(M * D);
     const int H0 = (int)shapes[0], W0 = (int)shapes[1];
-    const int HW0 = H0 * W0;
+    // level maps: nested (msda_sample.hpp), not necessarily exact halves -- sizes and query starts from the shape tensor
+    const int H1 = L > 1 ? (int)shapes[2] : 1, W1 = L > 1 ? (int)shapes[3] : 1, H2 = L > 2 ? (int)shapes[4] : 1, W2 = L > 2 ? (int)shapes[5] : 1;
+    const int H3 = L > 3 ? (int)shapes[6] : 1, W3 = L > 3 ? (int)shapes[7] : 1;
+    const int qs1 = H0 * W0, qs2 = qs1 + H1 * W1, qs3 = qs2 + H2 * W2;
     const int ntx0 = (W0 + 15) >> 4;
     const int n_tiles = ((H0 + 7) >> 3) * ntx0;
     const unsigned n_items = (unsigned)(B * M * n_tiles);
@@ -85,16 +88,17 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     const int cA0 = cA + (int)lds_addr(smem);      // ... as an LDS byte address
     const int qslot = (quad & 8) | ((0x46751320 >> ((quad & 7) * 4)) & 7);
     const int kk = min(k, L - 1);
-    const int Hk = H0 >> kk, Wk = W0 >> kk;
+    const int Hk = sel4(kk, H0, H1, H2, H3), Wk = sel4(kk, W0, W1, W2, W3);
     const int v0k = (int)lsi[kk];
     const int sub8 = lane & 7;                    // DMA: 16-byte chunk of the (pixel, head) row
-    int sinfo, sq0;
+    int sinfo, sq0, sH, sW;   // this lane's query slot: packed (level, y, x), first query of its level, the level's size
     {
         const int s = wave_s * 16 + qslot;
         const int rr = min((s >= 128) + (s >= 160) + (s >= 168), 3);
         const int lo = s - (rr == 0 ? 0 : rr == 1 ? 128 : rr == 2 ? 160 : 168);
         sinfo = rr | ((lo >> (4 - rr)) << 2) | ((lo & ((16 >> rr) - 1)) << 6) | ((s >= n_slots ? 1 : 0) << 10);
-        sq0 = (rr >= 1 ? HW0 : 0) + (rr >= 2 ? HW0 >> 2 : 0) + (rr >= 3 ? HW0 >> 4 : 0);
+        sq0 = sel4(rr, 0, qs1, qs2, qs3);
+        sH = sel4(rr, H0, H1, H2, H3); sW = sel4(rr, W0, W1, W2, W3);
     }
 
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
     auto pair_of = [&](int b, int m, int ty, int tx, bool &ok) -> unsigned {
         const int sr = sinfo & 3, sy = (sinfo >> 2) & 15, sx = (sinfo >> 6) & 15;
         const int y = ((ty * 8) >> sr) + sy, x = ((tx * 16) >> sr) + sx;
-        ok = !(sinfo >> 10) && y < (H0 >> sr) && x < (W0 >> sr);
-        const int q = ok ? sq0 + y * (W0 >> sr) + x : (ty * 8) * W0 + tx * 16;
+        ok = !(sinfo >> 10) && y < sH && x < sW;
+        const int q = ok ? sq0 + y * sW + x : (ty * 8) * W0 + tx * 16;
         return (unsigned)((b * Lq + q) * M + m);
     };
     float4_t lc0, lc1, la;   // this lane's level of the item AFTER the one being prepared: 4 x (x, y), 4 weights
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             const int y0 = __builtin_amdgcn_readlane(bxc.x, late_c), ny1 = __builtin_amdgcn_readlane(bxc.y, late_c);
             const int x0 = __builtin_amdgcn_readlane(bxc.z, late_c), nx1 = __builtin_amdgcn_readlane(bxc.w, late_c);
             const int ww = (-nx1 + 1) - x0 + 1, npix = ((-ny1 + 1) - y0 + 1) * ww;
-            const int Hl = H0 >> late_c, Wl = W0 >> late_c;
+            const int Hl = sel4(late_c, H0, H1, H2, H3), Wl = sel4(late_c, W0, W1, W2, W3);
             const unsigned magic = (1u << 20) / (unsigned)ww + 1u;
             const float *srcl = vbc + (size_t)__builtin_amdgcn_readlane(v0k, late_c) * MD;
             char *dst = smem + (T6_ZPX + (lay_l & 0xffff)) * 128;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             const int y0 = __builtin_amdgcn_readlane(bxn.x, l), x0 = __builtin_amdgcn_readlane(bxn.z, l);
             const int ww = (-__builtin_amdgcn_readlane(bxn.w, l) + 1) - x0 + 1;
             const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick, l);
-            const int Hl = uni(H0) >> l, Wl = uni(W0) >> l;
+            const int Hl = uni(sel4(l, H0, H1, H2, H3)), Wl = uni(sel4(l, W0, W1, W2, W3));
             const uint64_t lvl = (uint64_t)(uintptr_t)vbn + (uint64_t)(unsigned)__builtin_amdgcn_readlane(v0k, l) * (uint64_t)uni((int)MD) * 4u;
             const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void msda_fwd_tiled7_kernel(
             for (int l = 0; l < L; ++l) {
                 const int lay_l = __builtin_amdgcn_readlane(layc, l);
                 if (!((lay_l >> 25) & 1)) continue;
-                const int Hc = H0 >> l, Wc = W0 >> l;
+                const int Hc = sel4(l, H0, H1, H2, H3), Wc = sel4(l, W0, W1, W2, W3);
                 const float *vc = vbc + (size_t)__builtin_amdgcn_readlane(v0k, l) * MD;
                 const int src = ((lane & ~3) | l) << 2;
 #pragma unroll

@@ -6,17 +6,19 @@
 // point arithmetic, boxes, layout, window DMA addresses -- by VALU issue, and a block runs the two one after the other:
 // all twelve waves gather, then all twelve do arithmetic, so each pipe idles while the other one works.
 // Here the CU still belongs to ONE block of twelve waves, but an item is owned by a TEAM (six waves: 96 (query, head)
-// slots, so the 170 queries of an item take two passes) and the teams are two barrier intervals out of phase:
+// slots, so the 170 queries of an item take two passes) and the teams are half a period out of phase:
 //
-//      interval        team 0                             team 1
-//      4n              P1 points + boxes of item a        G0 gather pass 0 of item b
-//      4n + 1          P2 layout, offsets, window DMA     G1 gather pass 1 of item b
-//      4n + 2          G0 gather pass 0 of item a         P1 points + boxes of item b'
-//      4n + 3          G1 gather pass 1 of item a         P2 layout, offsets, window DMA of item b'
+//      half period     team 0                                        team 1
+//      2n              P1 points + boxes of item a | meeting point   G0, G1 gather of item b (both passes)
+//                      | P2 layout, offsets, window DMA of item a
+//      2n + 1          G0, G1 gather of item a                       P1 | meeting point | P2 of item b'
 //
+// ONE block barrier per half period (the swap); inside its preparing half a team meets at an LDS counter of its own (the boxes
+// need all six waves), so the other team's gather is never held up by it.
 // so in every interval one team loads the LDS pipe and the other one the VALU.  The arena of 1200 pixels is shared: team 0
 // places its windows from the bottom, team 1 from the top, each beside what the other team's item occupies at that
-// moment (s_used); a level that does not fit is gathered from global memory (no "late" levels here).  An item's windows
+// moment (s_used); ONE level that does not fit becomes "late" (placed in the space the other team's item frees at the swap, staged at
+// the start of the gathering half), any further one is gathered from global memory.  An item's windows
 // are requested in P2 and waited for at the barrier behind it (the other team's gather hides the wait for the CU, not for
 // the team).  Everything else -- pyramid items, a lane owns one level of its query, quad per (query, head), box reduction
 // by LDS integer minima, DMA rounds as scalar code with hardware zero fill -- is generation 7's and shares its helpers.
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_box = reinterpret_cast<int *>(smem + (T6_ZPX + R + T6_SLACK) * 128);   // [2 teams][4 levels][4]: min hl, min -hl, min wl, min -wl
     int *s_used = s_box + 32;                                                      // [2 teams]: pixels of the arena the team's item occupies
+    int *s_cnt = s_box + 34;                                                       // [2 meeting points][2 teams]: arrivals (monotonic)
 
     if (!geometry_is_pyramid(shapes, L, Lq)) {
         if (hinted) __builtin_trap();   // a stale "pyramid" hint must fail loudly, not leave `out` unwritten
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
     if (tid < 32) s_box[tid] = T6_BIG;
     if (tid < 2) s_used[tid] = 0;
+    if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
 
     const unsigned xcd = blockIdx.x & 7;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     const unsigned lim = xcd * ipx < n_items ? min(ipx, n_items - xcd * ipx) : 0u;
     const int n_blk = j0 < lim ? (int)((lim - j0 + blocks_per_xcd - 1) / blocks_per_xcd) : 0;
     if (n_blk == 0) return;   // (block-uniform)
-    const int nsteps = 4 * ((n_blk + 1) >> 1) + 2;
+    const int nsteps = 2 * ((n_blk + 1) >> 1) + 1;   // half periods: team 0 prepares in the even ones and gathers in the odd ones, team 1 the other way round
 
     auto pair_of = [&](int p, int b, int m, int ty, int tx, bool &ok) -> unsigned {
         const int sr = sinfo[p] & 3, sy = (sinfo[p] >> 2) & 15, sx = (sinfo[p] >> 6) & 15;
@@ -161,13 +165,11 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     int4 bx = {0, 0, 0, 0};
     int lay = 0;
 
-    // gather of one pass: every level of the 16 (query, head) slots of this wave, then the stores
+    // gather of one pass of the 16 (query, head) slots of this wave.  want = 1: the levels staged with the item (+ the levels that
+    // come from global memory), want = 5: the item's late level (staged at the start of the gathering half, see P2).
     auto gather = [&](const float (&w1c)[4], const float (&w2c)[4], const float (&w3c)[4], const float (&w4c)[4], const int (&oc)[4],
-                      bool qok, unsigned pr) {
+                      float (&acc)[8], int want) {
         const float *vbc = value + ((size_t)cb * S * M + cm) * D;
-        float acc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 #define T8_HOT_POINT(I_, LQ)                                                                                     \
     {                                                                                                            \
         const int b0 = qbi<LQ>(oc[I_]) + cA0, b1 = b0 ^ 64;                                                       \
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                           "+v"(acc[6]), "+v"(acc[7]));                                                           \
     }
 #define T8_LEVEL(LQ)                                                                                             \
-    if ((__builtin_amdgcn_readlane(lay, LQ) >> 24) & 1) {                                                        \
+    if (((__builtin_amdgcn_readlane(lay, LQ) >> 24) & 5) == want) {                                              \
         const int pitch = ((-__builtin_amdgcn_readlane(bx.w, LQ) + 1) - __builtin_amdgcn_readlane(bx.z, LQ) + 1) * 128; \
         T8_HOT_POINT(0, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
         T8_HOT_POINT(1, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
 #undef T8_LEVEL
 #undef T8_HOT_POINT
         // cold levels: from global memory, the owner lane's point data by ds_bpermute (run-time level)
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < (want == 1 ? L : 0); ++l) {
             const int lay_l = __builtin_amdgcn_readlane(lay, l);
             if (!((lay_l >> 25) & 1)) continue;
             const int Hc = H0 >> l, Wc = W0 >> l;
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
             }
             if (PROF) pacc[12] += 1;
         }
+    };
+    auto store_out = [&](const float (&acc)[8], bool qok, unsigned pr) {
         if (qok && !(T8_ABL & 8)) {
             if (out16) {   // the caller (the fused layer) wants the bf16 operand of output_proj
                 uint16_t *op = out16 + (size_t)pr * D;
@@ -259,8 +263,30 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
             }
         }
     };
+    // one round of window DMA: 8 pixels of level l, first window pixel pix0, to arena pixel `base` (+ pix0)
+    auto dma8 = [&](int l, int pix0, int base, const float *vb, unsigned magick_) {
+        const int y0 = __builtin_amdgcn_readlane(bx.x, l), x0 = __builtin_amdgcn_readlane(bx.z, l);
+        const int ww = (-__builtin_amdgcn_readlane(bx.w, l) + 1) - x0 + 1;
+        const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick_, l);
+        const int Hl = uni(H0) >> l, Wl = uni(W0) >> l;
+        const uint64_t lvl = (uint64_t)(uintptr_t)vb + (uint64_t)(unsigned)__builtin_amdgcn_readlane(v0k, l) * (uint64_t)uni((int)MD) * 4u;
+        const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
+                                                                             (int)(((unsigned)(Hl * Wl - 1) * (unsigned)uni((int)MD) + 32u) * 4u), 0x00020000);
+        const int pix = pix0 + (lane >> 3);
+        const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
+        const int gy = y0 + wy, gx = x0 + wx;
+        const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
+        const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
+        char *dst = smem + (size_t)(T6_ZPX + base + pix0) * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff, 0, 0, 0);
+    };
 
-    int ph = team * 2;            // team 1 enters at G0 with nothing in hand
+    int ph = team;                // 0: the preparing half (P1, P2), 1: the gathering half (G0, G1); team 1 enters gathering, with nothing in hand
+    int epoch = 0;                // items this team has prepared
+    int epoch_late = 0;           // ... of which had a late level
+    int late_l = -1, late_np = 0, late_base = 0;   // the current item's late level (or -1), its window size and arena position
+    unsigned magick_c = 0;        // pix / ww magic of this lane's level (window DMA), kept for the late level
     if (team == 0) prefetch_next();
     for (int step = 0; step < nsteps; ++step) {
         T8_TICK(0)   // barrier + loop control
@@ -300,9 +326,17 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 }
             }
             T8_TICK(1)
-        } else if (phu == 1) {
             // ================= P2: layout beside the other team's item, LDS offsets, window DMA =================
             if (cv) {
+                // the team's own meeting point (the boxes of all six waves are in): an LDS counter, not the block barrier -- the
+                // other team is in the middle of its gather and must not be held up.  The LDS executes a wave's operations in
+                // order, so a wave that sees the full count also sees every minimum that was issued in front of an arrival.
+                ++epoch;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(s_cnt + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(s_cnt + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch * TW) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                T8_TICK(8)   // team meeting point
                 bx = *reinterpret_cast<const int4 *>(s_box + team * 16 + k * 4);   // lane l < 4: the box of level l
                 const int used_other = uni(s_used[team ^ 1]);
                 const bool anyk = bx.x != T6_BIG && k < L;
@@ -311,17 +345,34 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 if (anyk && wwk > T6_ZPX - 2) np8k = 0x10000;
                 const unsigned magick = (1u << 20) / (unsigned)max(wwk, 1) + 1u;
                 int cum[5] = {0, 0, 0, 0, 0};
+                magick_c = magick;
                 {
+                    // Levels are placed on the team's side of the arena beside what the other team's item occupies NOW.  ONE level
+                    // that does not fit there becomes LATE: it is placed behind the team's other levels in the space the other
+                    // team's item leaves at the swap, reserved here (s_used) so that the other team's next layout keeps clear of
+                    // it, staged at the start of the gathering half and gathered behind a second meeting point.
                     const int limit = R - used_other;
                     int used = 0, lays[4];
+                    late_l = -1; late_np = 0;
 #pragma unroll
                     for (int l = 0; l < 4; ++l) {
                         const int np = __builtin_amdgcn_readlane(np8k, l);
                         const bool fits = np > 0 && used + np <= limit;
+                        const bool late = !fits && np > 0 && np <= R && late_l < 0;
                         const int base = team ? R - used - np : used;
                         lays[l] = fits ? (base | (1 << 24)) : (np > 0 ? (1 << 25) : 0);
                         used += fits ? np : 0;
                         cum[l + 1] = used;
+                        late_np = late ? np : late_np;
+                        late_l = late ? l : late_l;
+                    }
+                    if (late_l >= 0 && used + late_np <= R) {
+                        late_base = team ? R - used - late_np : used;
+                        const int v = late_base | (5 << 24);
+                        if (late_l == 0) lays[0] = v; else if (late_l == 1) lays[1] = v; else if (late_l == 2) lays[2] = v; else lays[3] = v;
+                        used += late_np;
+                    } else {
+                        late_l = -1;
                     }
                     lay = sel4(k, lays[0], lays[1], lays[2], lays[3]);
                     if (tid == team * (TW * 64)) s_used[team] = used;
@@ -344,49 +395,56 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 // window DMA: the hot windows are ONE concatenated list of 8-pixel groups, group g belongs to wave g % 6 of the team
                 if (!(T8_ABL & 4)) {
                     const float *vbn = value + ((size_t)cb * S * M + cm) * D;
-                    const int lpx = lane >> 3;
                     const int c1 = uni(cum[1]), c2 = uni(cum[2]), c3 = uni(cum[3]), c4 = uni(cum[4]);
                     for (int p0 = wt * 8; p0 < c4; p0 += TW * 8) {
                         const int l = (p0 >= c1) + (p0 >= c2) + (p0 >= c3);
                         const int pix0 = p0 - (l == 0 ? 0 : l == 1 ? c1 : l == 2 ? c2 : c3);
-                        const int lay_l = __builtin_amdgcn_readlane(lay, l);
-                        const int y0 = __builtin_amdgcn_readlane(bx.x, l), x0 = __builtin_amdgcn_readlane(bx.z, l);
-                        const int ww = (-__builtin_amdgcn_readlane(bx.w, l) + 1) - x0 + 1;
-                        const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick, l);
-                        const int Hl = uni(H0) >> l, Wl = uni(W0) >> l;
-                        const uint64_t lvl = (uint64_t)(uintptr_t)vbn + (uint64_t)(unsigned)__builtin_amdgcn_readlane(v0k, l) * (uint64_t)uni((int)MD) * 4u;
-                        const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
-                                                                                             (int)(((unsigned)(Hl * Wl - 1) * (unsigned)uni((int)MD) + 32u) * 4u), 0x00020000);
-                        const int pix = pix0 + lpx;
-                        const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
-                        const int gy = y0 + wy, gx = x0 + wx;
-                        const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
-                        const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
-                        char *dst = smem + (size_t)(T6_ZPX + (lay_l & 0xffff) + pix0) * 128;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff, 0, 0, 0);
+                        dma8(l, pix0, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick);
                     }
                 }
                 T8_TICK(3)   // DMA issue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
                 T8_TICK(4)   // DMA wait
             }
-        } else if (phu == 2) {
-            // ================= G0: pass 0 of the gather =================
+        } else {
+            // ================= G0, G1: the two passes of the gather =================
             if (tid - team * (TW * 64) < 16) s_box[team * 16 + (tid - team * (TW * 64))] = T6_BIG;   // read in P2, written again in the next P1
             T8_TICK(5)
-            if (cv) gather(w1[0], w2[0], w3[0], w4[0], o[0], qokc[0], prc[0]);
-            T8_TICK(6)
-        } else {
-            // ================= G1: pass 1 =================
-            if (cv) gather(w1[1], w2[1], w3[1], w4[1], o[1], qokc[1], prc[1]);
+            if (cv) {
+                const bool has_late = uni(late_l) >= 0;   // (team-uniform)
+                if (has_late && !(T8_ABL & 4)) {          // its DMA goes out first and lands under pass 0 of the other levels
+                    const float *vbc = value + ((size_t)cb * S * M + cm) * D;
+                    for (int p0 = wt * 8; p0 < uni(late_np); p0 += TW * 8) dma8(uni(late_l), p0, uni(late_base), vbc, magick_c);
+                }
+                float acc[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+                gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 1);
+                T8_TICK(6)
+                if (has_late) {
+                    ++epoch_late;
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the late window has landed
+                    if (lane == 0) __hip_atomic_fetch_add(s_cnt + 2 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while (__hip_atomic_load(s_cnt + 2 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch_late * TW) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 5);
+                    if (PROF) pacc[13] += 1;
+                }
+                store_out(acc, qokc[0], prc[0]);
+                T8_TICK(9)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+                gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 1);
+                if (has_late) gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 5);
+                store_out(acc, qokc[1], prc[1]);
+            }
             prefetch_next();   // the team's next item: its locations / weights travel across the barrier into P1
             if (PROF && cv) pacc[14] += 1;
             T8_TICK(7)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        ph = (ph + 1) & 3;
+        ph ^= 1;
     }
     if (PROF && lane == 0) {
 #pragma unroll

@@ -264,7 +264,7 @@ def shape_facts(spatial_shapes):
 
     The sum is the quantity the reference's modules compare with the value length on every call (ms_deform_attn.py:100,
     multi_scale_deform_attn.py:319, ...mask_dn.py:741) -- a host synchronisation per layer.  The same read-back tells
-    whether the level maps form an exact 2x pyramid (GEO_PYRAMID) or not (GEO_GENERAL), which lets the native operator
+    whether the level maps are nested halves -- an exact 2x pyramid or its ceil / floor-divided variants -- (GEO_PYRAMID) or not (GEO_GENERAL), which lets the native operator
     enqueue ONE kernel instead of two (vllm_msda_forward_f32_geo).  The det heads pass the SAME tensor object to every
     encoder / decoder layer, so the result is remembered per tensor object and autograd version (an in-place change bumps
     the version; a dead object's id can be reused, hence the weak reference): one synchronisation per forward pass instead
@@ -277,15 +277,27 @@ def shape_facts(spatial_shapes):
         return ent[2], ent[3]
     hw = spatial_shapes.detach().reshape(-1, 2).tolist()    # ONE device -> host copy
     total = sum(int(h) * int(w) for h, w in hw)
-    h0, w0 = (int(hw[0][0]), int(hw[0][1])) if hw else (0, 0)
-    pyramid = 1 <= len(hw) <= 4 and h0 > 0 and w0 > 0 and all(
-        (int(h) << l) == h0 and (int(w) << l) == w0 for l, (h, w) in enumerate(hw))
+    pyramid = nested_maps([(int(h), int(w)) for h, w in hw])
     geo = GEO_PYRAMID if pyramid else GEO_GENERAL
     if ver is not None:
         if len(_SHAPE_FACTS) >= 64:
             _SHAPE_FACTS.clear()
         _SHAPE_FACTS[key] = (weakref.ref(spatial_shapes), ver, total, geo)
     return total, geo
+
+
+def nested_maps(hw):
+    """The pyramid-item kernel's predicate (csrc/msda_sample.hpp, geometry_is_nested): 1-4 levels, each the previous one
+    halved, rounded either way -- exact 2x pyramids and the ceil-divided maps of a detection backbone (100x167, 50x84, ...)."""
+    if not 1 <= len(hw) <= 4 or hw[0][0] <= 0 or hw[0][1] <= 0:
+        return False
+    nty, ntx = (hw[0][0] + 7) >> 3, (hw[0][1] + 15) >> 4
+    for l in range(1, len(hw)):
+        (hp, wp), (h, w) = hw[l - 1], hw[l]
+        if not (h > 0 and w > 0 and hp >> 1 <= h <= (hp + 1) >> 1 and wp >> 1 <= w <= (wp + 1) >> 1 and
+                h <= nty * (8 >> l) and w <= ntx * (16 >> l)):
+            return False
+    return True
 
 
 def level_pixels(spatial_shapes):
