@@ -263,8 +263,11 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
             }
         }
     };
-    // one round of window DMA: 8 pixels of level l, first window pixel pix0, to arena pixel `base` (+ pix0)
-    auto dma8 = [&](int l, int pix0, int base, const float *vb, unsigned magick_) {
+    // window DMA of ONE level: its np pixels (a multiple of 8) to arena pixel `base`, in 8-pixel groups (1 KiB per wave instruction);
+    // this wave takes the groups g with (g + phase) % 6 == its index in the team.  Everything per level -- box, pitch, magic,
+    // buffer descriptor (out-of-map pixels get an offset beyond it: hardware zero fill) -- is set up once, the round itself is
+    // ~12 VALU on the lane's pixel + the load.
+    auto dma_level = [&](int l, int np, int base, const float *vb, unsigned magick_, int phase) {
         const int y0 = __builtin_amdgcn_readlane(bx.x, l), x0 = __builtin_amdgcn_readlane(bx.z, l);
         const int ww = (-__builtin_amdgcn_readlane(bx.w, l) + 1) - x0 + 1;
         const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick_, l);
@@ -273,13 +276,17 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
         const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
                                                                              (int)(((unsigned)(Hl * Wl - 1) * (unsigned)uni((int)MD) + 32u) * 4u), 0x00020000);
-        const int pix = pix0 + (lane >> 3);
-        const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
-        const int gy = y0 + wy, gx = x0 + wx;
-        const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
-        const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
-        char *dst = smem + (size_t)(T6_ZPX + base + pix0) * 128;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff, 0, 0, 0);
+        int g0 = wt - phase;            // first group of this wave: (g0 + phase) % 6 == wt
+        g0 += g0 < 0 ? TW : 0;
+        char *dst0 = smem + (size_t)(T6_ZPX + base) * 128;
+        for (int pix0 = uni(g0) * 8; pix0 < np; pix0 += TW * 8) {
+            const int pix = pix0 + (lane >> 3);
+            const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
+            const int gy = y0 + wy, gx = x0 + wx;
+            const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
+            const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + pix0 * 128), 16, (int)voff, 0, 0, 0);
+        }
     };
 
     int ph = team;                // 0: the preparing half (P1, P2), 1: the gathering half (G0, G1); team 1 enters gathering, with nothing in hand
@@ -395,11 +402,11 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 // window DMA: the hot windows are ONE concatenated list of 8-pixel groups, group g belongs to wave g % 6 of the team
                 if (!(T8_ABL & 4)) {
                     const float *vbn = value + ((size_t)cb * S * M + cm) * D;
-                    const int c1 = uni(cum[1]), c2 = uni(cum[2]), c3 = uni(cum[3]), c4 = uni(cum[4]);
-                    for (int p0 = wt * 8; p0 < c4; p0 += TW * 8) {
-                        const int l = (p0 >= c1) + (p0 >= c2) + (p0 >= c3);
-                        const int pix0 = p0 - (l == 0 ? 0 : l == 1 ? c1 : l == 2 ? c2 : c3);
-                        dma8(l, pix0, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick);
+                    // the hot windows, level by level; the groups of the concatenated list are dealt to the six waves round robin
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        const int np = uni(cum[l + 1]) - uni(cum[l]);
+                        if (np > 0) dma_level(l, np, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick, (uni(cum[l]) >> 3) % TW);
                     }
                 }
                 T8_TICK(3)   // DMA issue
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 const bool has_late = uni(late_l) >= 0;   // (team-uniform)
                 if (has_late && !(T8_ABL & 4)) {          // its DMA goes out first and lands under pass 0 of the other levels
                     const float *vbc = value + ((size_t)cb * S * M + cm) * D;
-                    for (int p0 = wt * 8; p0 < uni(late_np); p0 += TW * 8) dma8(uni(late_l), p0, uni(late_base), vbc, magick_c);
+                    dma_level(uni(late_l), uni(late_np), uni(late_base), vbc, magick_c, 0);
                 }
                 float acc[8];
 #pragma unroll
