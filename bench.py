@@ -168,9 +168,10 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         ab = msda_bytes(t)
         geo = A.known_geometry(t["shapes"], t["loc"].shape[1])
         if tag == "enc":
-            kern = {A.GEO_PYRAMID: "msda_fwd_tiled7_kernel<12 waves, 1 block per CU> (pyramid items; ONE launch: geometry known on the host)",
+            kern = {A.GEO_PYRAMID: "msda_fwd_tiled8_kernel<12 waves in two teams, 1 block per CU> (pyramid items; ONE launch: geometry known on the host)",
+                    A.GEO_NESTED: "msda_fwd_tiled8_kernel<nested maps> (pyramid items; one launch)",
                     A.GEO_GENERAL: "msda_fwd_tiled4_kernel (any-geometry LDS-tiled kernel; one launch)",
-                    A.GEO_UNKNOWN: "msda_fwd_tiled7_kernel + empty msda_fwd_tiled4_kernel launch (geometry decided on the device)"}[geo]
+                    A.GEO_UNKNOWN: "msda_fwd_tiled8_kernel + empty msda_fwd_tiled4_kernel launch (geometry decided on the device)"}[geo]
             kern += " fp32, D32, encoder shape Lq=S=37485, B=8"
             out[nm] = entry(ptag, kern, "hbm", ab, sec, n_launch, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab)
         else:
@@ -193,7 +194,7 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         tn["values"] = [tn["value"]]
         ab = msda_bytes(tn)
         geo_n = A.known_geometry(tn["shapes"], tn["loc"].shape[1])
-        kern_n = ("msda_fwd_tiled7_kernel (pyramid items on NESTED maps: ceil-divided levels" if geo_n == A.GEO_PYRAMID
+        kern_n = ("msda_fwd_tiled8_kernel (pyramid items on NESTED maps: ceil-divided levels" if geo_n in (A.GEO_PYRAMID, A.GEO_NESTED)
                   else "msda_fwd_tiled4_kernel (any-geometry kernel: levels")
         out["msda_nonpyramid"] = entry("-", kern_n + " 100x167 / 50x84 / 25x42 / 13x21, B=8, Lq=S)", "hbm",
                                        ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,

@@ -104,15 +104,16 @@ int vllm_msda_forward_f64(const double *value, const int64_t *shapes, const int6
                           int B, int S, int M, int D, int L, int Lq, int P,
                           double *out, vllm_stream_t stream);
 /* vllm_msda_forward_f32 for a caller that knows the level geometry on the HOST.  `shapes` is device memory (as in the
- * reference), so by itself the library cannot know whether the level maps form an exact 2x pyramid whose cells are the Lq
- * queries (the det heads' 168^2 / 84^2 / 42^2 / 21^2 encoder case, served by the pyramid-item kernel) without a host
- * synchronisation: VLLM_GEO_UNKNOWN enqueues the pyramid kernel AND the any-geometry kernel and the device picks (one
- * empty launch).  The reference's modules synchronise once per forward pass anyway (`(H * W).sum() == Len_in`,
+ * reference), so by itself the library cannot know whether the level maps are nested halves whose cells are the Lq
+ * queries (the det heads' 168^2 / 84^2 / 42^2 / 21^2 encoder case, or the ceil-divided 100x167 / 50x84 / ... of a detection
+ * backbone: served by the pyramid-item kernel) without a host synchronisation: VLLM_GEO_UNKNOWN enqueues the pyramid
+ * kernel's two instantiations AND the any-geometry kernel and the device picks (two empty launches).  The reference's modules synchronise once per forward pass anyway (`(H * W).sum() == Len_in`,
  * ms_deform_attn.py:100); the Python mirror learns the geometry in that same read-back and passes it here: exactly one
- * launch.  A PYRAMID hint that the device-side test contradicts traps (the hint is never trusted for addressing). */
+ * launch.  A PYRAMID / NESTED hint that the device-side test contradicts traps (the hint is never trusted for addressing). */
 #define VLLM_GEO_UNKNOWN 0
 #define VLLM_GEO_PYRAMID 1
 #define VLLM_GEO_GENERAL 2
+#define VLLM_GEO_NESTED 3   /* 1-4 levels, each the previous one halved, rounded either way (ceil- / floor-divided maps), not all exact */
 int vllm_msda_forward_f32_geo(const float *value, const int64_t *shapes, const int64_t *lsi,
                               const float *loc, const float *attw,
                               int B, int S, int M, int D, int L, int Lq, int P, int geometry,

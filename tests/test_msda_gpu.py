@@ -126,7 +126,7 @@ def test_tiled_kernel_matches_gather_kernel(mode):
     try:
         plain = _run(g)
         ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-        for variant in (1, 18, 17, 2, 3, 5, 8, 9):  # automatic (generation 7 on pyramids, else 4); 17: generation 6; (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
+        for variant in (1, 15, 17, 2, 3, 5, 8, 9):  # automatic (generation 8 on nested maps, else 4); 15: generation 7; 17: generation 6; (generation 6 on pyramids, else 4), generation 4 (8 waves), 2, 4 + phase clock, 4 (560 / 2), 4 (360 / 3)
             _lib.set_option("msda_tiled", variant)
             tiled = _run(g)
             again = _run(g)
@@ -176,7 +176,7 @@ def test_generation6_pyramid_items(name, mode):
     try:
         plain = _run(g)
         res = {}
-        for variant in (1, 18, 17):   # automatic = generation 7 (software pipeline across items); generation 8 (two teams); generation 6
+        for variant in (1, 15, 17):   # automatic = generation 8 (two teams half a period apart); generation 7 (software pipeline across items); generation 6
             _lib.set_option("msda_tiled", variant)
             res[variant] = (_run(g), _run(g))
     finally:
@@ -830,7 +830,8 @@ def test_geometry_hint_changes_launches_not_results(shapes):
     geo = A.remember_geometry(ss)
     is_pyr = A.nested_maps(shapes)   # exact halves or ceil- / floor-divided levels; (31, 42) -> (9, 5) is neither
     assert is_pyr == (shapes[-1] != (9, 5))
-    assert geo == (A.GEO_PYRAMID if is_pyr else A.GEO_GENERAL) and A.known_geometry(ss, Lq) == geo
+    exact = shapes[0] == (72, 64)
+    assert geo == (A.GEO_PYRAMID if exact else A.GEO_NESTED if is_pyr else A.GEO_GENERAL) and A.known_geometry(ss, Lq) == geo
     assert A.known_geometry(ss, Lq - 1) == (A.GEO_GENERAL if is_pyr else geo)   # a pyramid only for the encoder's queries
     hinted = A.ms_deform_attn_forward(v, ss, lsi, loc, w, 64)
     assert torch.equal(hinted, unknown)

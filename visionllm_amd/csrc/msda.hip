@@ -538,8 +538,8 @@ extern "C" int vllm_msda_forward_f32_geo(const float *value, const int64_t *shap
                                          int Lq, int P, int geometry, float *out, vllm_stream_t stream)
 {
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
-    VLLM_REQUIRE(geometry == VLLM_GEO_UNKNOWN || geometry == VLLM_GEO_PYRAMID || geometry == VLLM_GEO_GENERAL,
-                 "msda_forward_f32: geometry must be VLLM_GEO_UNKNOWN / _PYRAMID / _GENERAL (got %d)", geometry);
+    VLLM_REQUIRE(geometry == VLLM_GEO_UNKNOWN || geometry == VLLM_GEO_PYRAMID || geometry == VLLM_GEO_GENERAL || geometry == VLLM_GEO_NESTED,
+                 "msda_forward_f32: geometry must be VLLM_GEO_UNKNOWN / _PYRAMID / _GENERAL / _NESTED (got %d)", geometry);
     if ((long)B * Lq == 0) return VLLM_OK;
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;

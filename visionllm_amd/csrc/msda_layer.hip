@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 {
     // shapes != null: the operator already wrote bf16 for a pyramid geometry (msda_forward_f32_out16) -- nothing to do then.
     // Grid-stride over a fixed grid, so that this "nothing" costs a couple of microseconds instead of 75 k empty blocks.
-    if (shapes && geometry_is_nested(shapes, L, Lq)) return;   // (the predicate of the generation-7 kernel, which then wrote bf16 itself)
+    if (shapes && geometry_is_nested(shapes, L, Lq)) return;   // (the predicate of the pyramid-item kernels, which then wrote bf16 themselves)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4_t v = reinterpret_cast<const float4_t *>(src)[i];
         uint2_t o;
@@ -269,7 +269,7 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st, d->geometry));
     // output_proj (:144).  The conversion pass runs unless the host KNOWS the operator wrote bf16 (pyramid hint); with an
     // unknown geometry it is enqueued and tests the device-side predicate itself.
-    if (!(where && d->geometry == VLLM_GEO_PYRAMID))
+    if (!(where && (d->geometry == VLLM_GEO_PYRAMID || d->geometry == VLLM_GEO_NESTED)))
         TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
     TRY(gemm(st, EPI_BIAS, opb, C, d->output_proj_w, C, d->output_proj_b, out, C, B * Lq, C, C));
     prof_mark(PT_END, st);

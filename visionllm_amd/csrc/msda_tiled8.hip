@@ -48,7 +48,9 @@ __device__ unsigned long long g_t8_prof[16];
         tprev = now__;                                                           \
     }
 
-template <int WIN, bool PROF>
+// EXACT: the level maps are exact halves (H_l << l == H_0): sizes by shifts, nothing per level held or loaded -- the kernel sits at
+// its SGPR budget, and the general form (sizes of nested maps from LDS) costs it 5 % on the shapes that do not need it.
+template <int WIN, bool PROF, bool EXACT>
 __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     int *s_used = s_box + 32;                                                      // [2 teams]: pixels of the arena the team's item occupies
     int *s_cnt = s_box + 34;                                                       // [2 meeting points][2 teams]: arrivals (monotonic)
 
-    if (!geometry_is_pyramid(shapes, L, Lq)) {
+    if (EXACT ? !geometry_is_pyramid(shapes, L, Lq) : !(geometry_is_nested(shapes, L, Lq) && !geometry_is_pyramid(shapes, L, Lq))) {
         if (hinted) __builtin_trap();   // a stale "pyramid" hint must fail loudly, not leave `out` unwritten
         return;
     }
@@ -73,7 +75,16 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     const int k = lane & 3;                       // the value level this lane owns
     const unsigned MD = (unsigned)(M * D);
     const int H0 = (int)shapes[0], W0 = (int)shapes[1];
-    const int HW0 = H0 * W0;
+    // level maps: nested (msda_sample.hpp), not necessarily exact halves -- sizes and query starts come from the shape tensor and
+    // live in LDS (s_dim: H[4], W[4], first query[4]); eleven more scalars held across the item loop cost the kernel its SGPR budget
+    int *s_dim = s_box + 40;
+    if (!EXACT && tid < 4) {
+        int q0 = 0;
+        for (int l = 0; l < tid; ++l) q0 += (l < L) ? (int)shapes[2 * l] * (int)shapes[2 * l + 1] : 0;
+        s_dim[tid] = tid < L ? (int)shapes[2 * tid] : 1;
+        s_dim[4 + tid] = tid < L ? (int)shapes[2 * tid + 1] : 1;
+        s_dim[8 + tid] = q0;
+    }
     const int ntx0 = (W0 + 15) >> 4;
     const int n_tiles = ((H0 + 7) >> 3) * ntx0;
     const unsigned n_items = (unsigned)(B * M * n_tiles);
@@ -86,17 +97,16 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     const int cA0 = cA + (int)lds_addr(smem);
     const int qslot = (quad & 8) | ((0x46751320 >> ((quad & 7) * 4)) & 7);
     const int kk = min(k, L - 1);
-    const int Hk = H0 >> kk, Wk = W0 >> kk;
+    const int Hk = EXACT ? H0 >> kk : (int)shapes[2 * kk], Wk = EXACT ? W0 >> kk : (int)shapes[2 * kk + 1];
     const int v0k = (int)lsi[kk];
     const int sub8 = lane & 7;
-    int sinfo[2], sq0[2];
+    int sinfo[2];   // per pass, this lane's query slot: packed (level, y, x, dead)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int s = p * (TW * 16) + wt * 16 + qslot;
         const int rr = min((s >= 128) + (s >= 160) + (s >= 168), 3);
         const int lo = s - (rr == 0 ? 0 : rr == 1 ? 128 : rr == 2 ? 160 : 168);
         sinfo[p] = rr | ((lo >> (4 - rr)) << 2) | ((lo & ((16 >> rr) - 1)) << 6) | ((s >= n_slots ? 1 : 0) << 10);
-        sq0[p] = (rr >= 1 ? HW0 : 0) + (rr >= 2 ? HW0 >> 2 : 0) + (rr >= 3 ? HW0 >> 4 : 0);
     }
 
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
@@ -118,8 +128,11 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     auto pair_of = [&](int p, int b, int m, int ty, int tx, bool &ok) -> unsigned {
         const int sr = sinfo[p] & 3, sy = (sinfo[p] >> 2) & 15, sx = (sinfo[p] >> 6) & 15;
         const int y = ((ty * 8) >> sr) + sy, x = ((tx * 16) >> sr) + sx;
-        ok = !(sinfo[p] >> 10) && y < (H0 >> sr) && x < (W0 >> sr);
-        const int q = ok ? sq0[p] + y * (W0 >> sr) + x : (ty * 8) * W0 + tx * 16;
+        const int HW0 = H0 * W0;
+        const int sH = EXACT ? H0 >> sr : s_dim[sr], sW = EXACT ? W0 >> sr : s_dim[4 + sr];   // (once per item and pass)
+        const int sQ = EXACT ? (sr >= 1 ? HW0 : 0) + (sr >= 2 ? HW0 >> 2 : 0) + (sr >= 3 ? HW0 >> 4 : 0) : s_dim[8 + sr];
+        ok = !(sinfo[p] >> 10) && y < sH && x < sW;
+        const int q = ok ? sQ + y * sW + x : (ty * 8) * W0 + tx * 16;
         return (unsigned)((b * Lq + q) * M + m);
     };
     auto decode = [&](unsigned item, int &b, int &m, int &ty, int &tx) {
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
         for (int l = 0; l < (want == 1 ? L : 0); ++l) {
             const int lay_l = __builtin_amdgcn_readlane(lay, l);
             if (!((lay_l >> 25) & 1)) continue;
-            const int Hc = H0 >> l, Wc = W0 >> l;
+            const int Hc = EXACT ? H0 >> l : uni(s_dim[l]), Wc = EXACT ? W0 >> l : uni(s_dim[4 + l]);
             const float *vc = vbc + (size_t)__builtin_amdgcn_readlane(v0k, l) * MD;
             const int src = ((lane & ~3) | l) << 2;
 #pragma unroll
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
         const int y0 = __builtin_amdgcn_readlane(bx.x, l), x0 = __builtin_amdgcn_readlane(bx.z, l);
         const int ww = (-__builtin_amdgcn_readlane(bx.w, l) + 1) - x0 + 1;
         const unsigned magic = (unsigned)__builtin_amdgcn_readlane((int)magick_, l);
-        const int Hl = uni(H0) >> l, Wl = uni(W0) >> l;
+        const int Hl = EXACT ? uni(H0) >> l : uni(s_dim[l]), Wl = EXACT ? uni(W0) >> l : uni(s_dim[4 + l]);
         const uint64_t lvl = (uint64_t)(uintptr_t)vb + (uint64_t)(unsigned)__builtin_amdgcn_readlane(v0k, l) * (uint64_t)uni((int)MD) * 4u;
         const uint64_t lvl_u = ((uint64_t)(unsigned)uni((int)(lvl >> 32)) << 32) | (unsigned)uni((int)(unsigned)lvl);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)lvl_u, 0,
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     }
 }
 
-template <int WIN, bool PROF>
+template <int WIN, bool PROF, bool EXACT>
 int t8_go(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B, int S,
           int M, int L, int Lq, float *out, uint16_t *out16, int hinted, hipStream_t st)
 {
@@ -474,10 +487,10 @@ int t8_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
     static_assert(lds <= 163840, "LDS budget");
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled8_kernel<WIN, PROF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled8_kernel<WIN, PROF, EXACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    VLLM_LAUNCH((msda_fwd_tiled8_kernel<WIN, PROF>), dim3((cus / 8) * 8), dim3(768), lds, st, value, shapes, lsi, loc, attw,
+    VLLM_LAUNCH((msda_fwd_tiled8_kernel<WIN, PROF, EXACT>), dim3((cus / 8) * 8), dim3(768), lds, st, value, shapes, lsi, loc, attw,
                 B, S, M, L, Lq, out, out16, hinted);
     VLLM_CHECK_LAUNCH("msda_fwd_tiled8_kernel");
     return VLLM_OK;
@@ -485,11 +498,21 @@ int t8_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
 
 }  // namespace
 
+// which: 1 the exact-pyramid instantiation, 2 the nested-maps one (each returns at once on maps that are not its own), 3 both
 int msda_tiled8_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted)
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted, int which)
 {
-    if (prof) return t8_go<1200, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
-    return t8_go<1200, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
+    if (which & 1) {
+        const int e = prof ? t8_go<1200, true, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st)
+                           : t8_go<1200, false, true>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
+        if (e) return e;
+    }
+    if (which & 2) {
+        const int e = prof ? t8_go<1200, true, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st)
+                           : t8_go<1200, false, false>(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, out16, hinted, st);
+        if (e) return e;
+    }
+    return VLLM_OK;
 }
 
 int msda8_debug_counters(long *out, int n)
@@ -509,7 +532,7 @@ int msda8_debug_counters(long *out, int n)
 extern "C" int t8_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B,
                           int S, int M, int L, int Lq, float *out, void *stream)
 {
-    return msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, (hipStream_t)stream, nullptr, 1);
+    return msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, (hipStream_t)stream, nullptr, 1, 1);
 }
 void set_error(const char *, ...) {}
 #endif

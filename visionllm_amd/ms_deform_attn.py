@@ -247,7 +247,7 @@ def msda_layer_fused_ok(query, input_flatten, *linears, reference_points=None):
     return d_model % 64 == 0 and all(lin.weight.dtype == torch.bfloat16 and lin.bias is not None for lin in linears)
 
 
-GEO_UNKNOWN, GEO_PYRAMID, GEO_GENERAL = 0, 1, 2   # VLLM_GEO_* of include/vllm_hip.h
+GEO_UNKNOWN, GEO_PYRAMID, GEO_GENERAL, GEO_NESTED = 0, 1, 2, 3   # VLLM_GEO_* of include/vllm_hip.h
 _SHAPE_FACTS = {}   # id(spatial_shapes) -> (weakref, tensor version, sum of H * W, geometry)
 
 
@@ -264,7 +264,7 @@ def shape_facts(spatial_shapes):
 
     The sum is the quantity the reference's modules compare with the value length on every call (ms_deform_attn.py:100,
     multi_scale_deform_attn.py:319, ...mask_dn.py:741) -- a host synchronisation per layer.  The same read-back tells
-    whether the level maps are nested halves -- an exact 2x pyramid or its ceil / floor-divided variants -- (GEO_PYRAMID) or not (GEO_GENERAL), which lets the native operator
+    whether the level maps are an exact 2x pyramid (GEO_PYRAMID), its ceil / floor-divided variants (GEO_NESTED) or neither (GEO_GENERAL), which lets the native operator
     enqueue ONE kernel instead of two (vllm_msda_forward_f32_geo).  The det heads pass the SAME tensor object to every
     encoder / decoder layer, so the result is remembered per tensor object and autograd version (an in-place change bumps
     the version; a dead object's id can be reused, hence the weak reference): one synchronisation per forward pass instead
@@ -277,8 +277,9 @@ def shape_facts(spatial_shapes):
         return ent[2], ent[3]
     hw = spatial_shapes.detach().reshape(-1, 2).tolist()    # ONE device -> host copy
     total = sum(int(h) * int(w) for h, w in hw)
-    pyramid = nested_maps([(int(h), int(w)) for h, w in hw])
-    geo = GEO_PYRAMID if pyramid else GEO_GENERAL
+    dims = [(int(h), int(w)) for h, w in hw]
+    exact = nested_maps(dims) and all((h << l) == dims[0][0] and (w << l) == dims[0][1] for l, (h, w) in enumerate(dims))
+    geo = GEO_PYRAMID if exact else GEO_NESTED if nested_maps(dims) else GEO_GENERAL
     if ver is not None:
         if len(_SHAPE_FACTS) >= 64:
             _SHAPE_FACTS.clear()
@@ -313,7 +314,7 @@ def known_geometry(spatial_shapes, num_queries):
     ent = _SHAPE_FACTS.get(id(spatial_shapes))
     if ver is None or ent is None or ent[0]() is not spatial_shapes or ent[1] != ver:
         return GEO_UNKNOWN
-    if ent[3] == GEO_PYRAMID and ent[2] != num_queries:
+    if ent[3] in (GEO_PYRAMID, GEO_NESTED) and ent[2] != num_queries:
         return GEO_GENERAL
     return ent[3]
 
