@@ -35,6 +35,9 @@
 #ifndef T8_ABL
 #define T8_ABL 0
 #endif
+#ifndef T8_EARLY      // levels of pass 0 a team gathers at the end of its preparing half (0: none; measured with 2: 500 vs 465 us -- the eight sums carried across the swap spill)
+#define T8_EARLY 0
+#endif
 
 namespace vllm {
 
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
     if (tid < 32) s_box[tid] = T6_BIG;
     if (tid < 2) s_used[tid] = 0;
-    if (tid < 4) s_cnt[tid] = 0;
+    if (tid < 6) s_cnt[tid] = 0;
     __syncthreads();
 
     const unsigned xcd = blockIdx.x & 7;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     // gather of one pass of the 16 (query, head) slots of this wave.  want = 1: the levels staged with the item (+ the levels that
     // come from global memory), want = 5: the item's late level (staged at the start of the gathering half, see P2).
     auto gather = [&](const float (&w1c)[4], const float (&w2c)[4], const float (&w3c)[4], const float (&w4c)[4], const int (&oc)[4],
-                      float (&acc)[8], int want) {
+                      float (&acc)[8], int want, int lmin, int lmax) {
         const float *vbc = value + ((size_t)cb * S * M + cm) * D;
 #define T8_HOT_POINT(I_, LQ)                                                                                     \
     {                                                                                                            \
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                           "+v"(acc[6]), "+v"(acc[7]));                                                           \
     }
 #define T8_LEVEL(LQ)                                                                                             \
-    if (((__builtin_amdgcn_readlane(lay, LQ) >> 24) & 5) == want) {                                              \
+    if (LQ >= lmin && LQ < lmax && ((__builtin_amdgcn_readlane(lay, LQ) >> 24) & 5) == want) {                   \
         const int pitch = ((-__builtin_amdgcn_readlane(bx.w, LQ) + 1) - __builtin_amdgcn_readlane(bx.z, LQ) + 1) * 128; \
         T8_HOT_POINT(0, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
         T8_HOT_POINT(1, LQ) __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
 #undef T8_LEVEL
 #undef T8_HOT_POINT
         // cold levels: from global memory, the owner lane's point data by ds_bpermute (run-time level)
-        for (int l = 0; l < (want == 1 ? L : 0); ++l) {
+        for (int l = 0; l < (want == 1 && lmax == 4 ? L : 0); ++l) {
             const int lay_l = __builtin_amdgcn_readlane(lay, l);
             if (!((lay_l >> 25) & 1)) continue;
             const int Hc = EXACT ? H0 >> l : uni(s_dim[l]), Wc = EXACT ? W0 >> l : uni(s_dim[4 + l]);
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
     int ph = team;                // 0: the preparing half (P1, P2), 1: the gathering half (G0, G1); team 1 enters gathering, with nothing in hand
     int epoch = 0;                // items this team has prepared
     int epoch_late = 0;           // ... of which had a late level
+    float acc0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // pass 0's sums of the levels gathered before the swap
     int late_l = -1, late_np = 0, late_base = 0;   // the current item's late level (or -1), its window size and arena position
     unsigned magick_c = 0;        // pix / ww magic of this lane's level (window DMA), kept for the late level
     if (team == 0) prefetch_next();
@@ -425,6 +429,19 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 T8_TICK(3)   // DMA issue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
                 T8_TICK(4)   // DMA wait
+                // The preparing half is the shorter one (the other team's two gather passes set the pace): the team starts on its
+                // own gather as soon as ITS windows are in -- a second meeting point of the team, no block barrier: the first
+                // T8_EARLY levels of pass 0 (the staged ones; a late level and anything from global memory wait for the swap).
+                if (T8_EARLY > 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(s_cnt + 4 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while (__hip_atomic_load(s_cnt + 4 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch * TW) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc0[c] = 0.f;
+                    gather(w1[0], w2[0], w3[0], w4[0], o[0], acc0, 1, 0, T8_EARLY);
+                    T8_TICK(10)   // early gather
+                }
             }
         } else {
             // ================= G0, G1: the two passes of the gather =================
@@ -438,8 +455,8 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 }
                 float acc[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-                gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 1);
+                for (int c = 0; c < 8; ++c) acc[c] = T8_EARLY > 0 ? acc0[c] : 0.f;
+                gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 1, T8_EARLY, 4);
                 T8_TICK(6)
                 if (has_late) {
                     ++epoch_late;
@@ -447,15 +464,15 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                     if (lane == 0) __hip_atomic_fetch_add(s_cnt + 2 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     while (__hip_atomic_load(s_cnt + 2 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch_late * TW) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
-                    gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 5);
+                    gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 5, 0, 4);
                     if (PROF) pacc[13] += 1;
                 }
                 store_out(acc, qokc[0], prc[0]);
                 T8_TICK(9)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-                gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 1);
-                if (has_late) gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 5);
+                gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 1, 0, 4);
+                if (has_late) gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 5, 0, 4);
                 store_out(acc, qokc[1], prc[1]);
             }
             prefetch_next();   // the team's next item: its locations / weights travel across the barrier into P1
