@@ -7,6 +7,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 export TMPDIR=/tmp
+make -C visionllm_amd/csrc -j16 2>&1 | tail -1   # (a stale .so once produced a wrong figure: rebuild whatever is out of date)
 O=gpurun_out/r03z
 mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt
