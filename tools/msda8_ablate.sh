@@ -1,0 +1,13 @@
+#!/bin/bash
+# Timing-only ablation builds of msda_tiled8.hip (one small shared library per mask) -> visionllm_amd/_build_abl/
+# Usage: tools/msda8_ablate.sh [mask ...]   (default: 0 1 2 3 4 8 16 20 32)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p visionllm_amd/_build_abl
+MASKS="${@:-0 1 2 3 4 8 16 20 32}"
+for m in $MASKS; do
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -fno-slp-vectorize -DT8_ABL=$m -DT7_OLD_PLACEMENT=$((m / 1024)) -DT8_ABL_ENTRY \
+      -o visionllm_amd/_build_abl/libmsda8_abl$m.so visionllm_amd/csrc/msda_tiled8.hip 2>&1 | grep -E "error|spill" || true ) &
+done
+wait
+ls visionllm_amd/_build_abl/ | grep msda8

@@ -35,6 +35,9 @@
 #ifndef T8_ABL
 #define T8_ABL 0
 #endif
+#ifndef T8_GPRIO      // s_setprio of a wave while it gathers (0: none; measured on one box each: 2: 453 vs 469 us, 3: 466 vs 477)
+#define T8_GPRIO 2
+#endif
 #ifndef T8_EARLY      // levels of pass 0 a team gathers at the end of its preparing half (0: none; measured with 2: 500 vs 465 us -- the eight sums carried across the swap spill)
 #define T8_EARLY 0
 #endif
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
             if (tid - team * (TW * 64) < 16) s_box[team * 16 + (tid - team * (TW * 64))] = T6_BIG;   // read in P2, written again in the next P1
             T8_TICK(5)
             if (cv) {
+                if (T8_GPRIO) __builtin_amdgcn_s_setprio(T8_GPRIO);   // the gathering half is the longer one: its waves go first on a SIMD they share
                 const bool has_late = uni(late_l) >= 0;   // (team-uniform)
                 if (has_late && !(T8_ABL & 4)) {          // its DMA goes out first and lands under pass 0 of the other levels
                     const float *vbc = value + ((size_t)cb * S * M + cm) * D;
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 1, 0, 4);
                 if (has_late) gather(w1[1], w2[1], w3[1], w4[1], o[1], acc, 5, 0, 4);
                 store_out(acc, qokc[1], prc[1]);
+                if (T8_GPRIO) __builtin_amdgcn_s_setprio(0);
             }
             prefetch_next();   // the team's next item: its locations / weights travel across the barrier into P1
             if (PROF && cv) pacc[14] += 1;
