@@ -22,7 +22,7 @@ find $O -name '*kernel_trace*' -delete
 find $O/prof_v $O/prof_i -type f -size +1M -delete
 (cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/fetch -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
-python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -30
+python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -30   # copy to profiles/pmc_traffic.json: bench.py reads `traffic` from there
 find $O/fetch $O/write -name '*.csv' -size +2M -delete
 python tools/msda_bwd_phases.py libmsdabwd_mfma_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_mfma_phases.txt
 python tools/msda_bwd_phases.py libmsdabwd_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_lds_phases.txt

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
     const int nchunk = C >> 3;
     const uint16_t *xr = x + r * (long)ldx + (long)grp * C;
 
+    // (weight / bias are requested behind the statistics, in the store loop: asking for them together with the row -- they do not
+    //  depend on the statistics -- measured 22.8 instead of 21.5 us per launch inside the ViT-L step, same box, round 3)
     uint4_t v[MAXCH];
     float s = 0.f, ss = 0.f;
 #pragma unroll
