@@ -93,3 +93,32 @@ def test_level_pixels_is_remembered_per_tensor_object_and_version():
     import pytest
     with pytest.raises(AssertionError):            # the module's check still fires (ms_deform_attn.py:100)
         mod(q, torch.rand(1, 5, 2, 2), src, fresh, torch.tensor([0, 7]), None)
+
+
+def test_level_geometry_facts_on_the_host():
+    """Host side of the MSDA geometry hint (ms_deform_attn.shape_facts / known_geometry / nested_maps): exact 2x pyramids,
+    ceil- / floor-divided maps (what the pyramid-item kernel's nested instantiation serves), everything else; the answer is
+    remembered per tensor object and version, only for the encoder's query count, and dropped on an in-place change.
+    The constants equal the header's."""
+    import re
+    import torch
+    from visionllm_amd import ms_deform_attn as A
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vllm_hip.h")).read()
+    for name, val in (("UNKNOWN", A.GEO_UNKNOWN), ("PYRAMID", A.GEO_PYRAMID), ("GENERAL", A.GEO_GENERAL), ("NESTED", A.GEO_NESTED)):
+        assert int(re.search(rf"#define VLLM_GEO_{name} (\d+)", hdr).group(1)) == val
+    assert A.nested_maps([(168, 168), (84, 84), (42, 42), (21, 21)])
+    assert A.nested_maps([(100, 167), (50, 84), (25, 42), (13, 21)])          # ceil-divided
+    assert A.nested_maps([(51, 83), (25, 41), (12, 20), (6, 10)])             # floor-divided
+    assert A.nested_maps([(72, 64)]) and not A.nested_maps([])
+    assert not A.nested_maps([(61, 83), (31, 42), (9, 5)])                    # not halves
+    assert not A.nested_maps([(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)])  # five levels
+    assert not A.nested_maps([(64, 64), (33, 32)])                            # 33 > ceil(64 / 2)
+    for shapes, geo in (([(72, 64), (36, 32)], A.GEO_PYRAMID), ([(50, 83), (25, 42)], A.GEO_NESTED), ([(50, 83), (20, 42)], A.GEO_GENERAL)):
+        t = torch.tensor(shapes, dtype=torch.int64)
+        lq = sum(h * w for h, w in shapes)
+        assert A.known_geometry(t, lq) == A.GEO_UNKNOWN
+        assert A.shape_facts(t) == (lq, geo)
+        assert A.known_geometry(t, lq) == geo
+        assert A.known_geometry(t, lq - 1) == A.GEO_GENERAL                   # the pyramid-item kernel serves the encoder's queries only
+        t.mul_(1)
+        assert A.known_geometry(t, lq) == A.GEO_UNKNOWN
