@@ -308,6 +308,15 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
         }
     };
 
+    // a team's meeting point: wait until `target` arrivals have been counted.  Bounded: the six waves of a team always take the same
+    // path, so the count always comes -- but a mistake here must end as a failed launch, not as a hung device
+    auto meet = [&](int *cnt, int target) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+    };
     int ph = team;                // 0: the preparing half (P1, P2), 1: the gathering half (G0, G1); team 1 enters gathering, with nothing in hand
     int epoch = 0;                // items this team has prepared
     int epoch_late = 0;           // ... of which had a late level
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 ++epoch;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(s_cnt + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                while (__hip_atomic_load(s_cnt + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch * TW) __builtin_amdgcn_s_sleep(1);
+                meet(s_cnt + team, epoch * TW);
                 asm volatile("" ::: "memory");
                 T8_TICK(8)   // team meeting point
                 bx = *reinterpret_cast<const int4 *>(s_box + team * 16 + k * 4);   // lane l < 4: the box of level l
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                 if (T8_EARLY > 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(s_cnt + 4 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while (__hip_atomic_load(s_cnt + 4 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch * TW) __builtin_amdgcn_s_sleep(1);
+                    meet(s_cnt + 4 + team, epoch * TW);
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int c = 0; c < 8; ++c) acc0[c] = 0.f;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
                     ++epoch_late;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the late window has landed
                     if (lane == 0) __hip_atomic_fetch_add(s_cnt + 2 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while (__hip_atomic_load(s_cnt + 2 + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch_late * TW) __builtin_amdgcn_s_sleep(1);
+                    meet(s_cnt + 2 + team, epoch_late * TW);
                     asm volatile("" ::: "memory");
                     gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, 5, 0, 4);
                     if (PROF) pacc[13] += 1;
