@@ -1,4 +1,5 @@
-// Multi-scale deformable attention forward, LDS-tiled kernel, generation 6 ("msda_tiled" option 1 = automatic, the default).
+// Multi-scale deformable attention forward, LDS-tiled kernel, generation 6 ("msda_tiled" options 10-14 / 17; it serves the bf16-value
+// operator vllm_msda_forward_bf16; for fp32 values the automatic choice is generation 8 since round 3, msda_tiled8.hip).
 //
 // Generation 4 (msda_tiled4.hip) spends two thirds of its time in the per-(tile, level) skeleton: point arithmetic,
 // bounding-box reduction + exchange, two barriers, one DMA wait -- four times per item.  This kernel does that work ONCE

@@ -1,5 +1,5 @@
-// Multi-scale deformable attention forward, LDS-tiled kernel, generation 7: generation 6's pyramid items (msda_tiled6.hip)
-// in a software pipeline across items.
+// Multi-scale deformable attention forward, LDS-tiled kernel, generation 7 ("msda_tiled" 15 / 16; the round-2 default -- round 3's is
+// generation 8, msda_tiled8.hip): generation 6's pyramid items (msda_tiled6.hip) in a software pipeline across items.
 //
 // What the phase clock of generation 6 showed (profiles/r02_msda6_phases.txt): per item a block spends a quarter of its
 // time issuing / waiting for the window DMA (a CU pulls ~25 GB/s through the LDS-DMA path, the windows of an item are
