@@ -258,6 +258,22 @@ int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias
                       const uint16_t *scale, const uint16_t *res, int ldr, int P,
                       void *scratch, long scratch_bytes, vllm_stream_t stream);
 
+/* The same GEMM with a LayerNorm / RMSNorm folded into it (8-phase schedule only; what vllm_vit_forward does between the
+ * residual GEMMs and the qkv / fc1 GEMMs instead of launching the norm, modeling_intern_vit.py:198-210 / CLIPEncoderLayer):
+ *   producer (ln_out != NULL): besides Y it writes, per output row and 256-column tile, {mean, M2 = sum (y - mean)^2} of the
+ *     bf16 values it stored ({sum y^2, 0} with ln_rms) to ln_out [M][ceil(N / 256)][2] (fp32);
+ *   consumer (ln_in != NULL): X holds the UN-normalised rows (K elements each, 768 < K <= 1024: ln_slots == 4), ln_in their
+ *     statistics [M][4][2] as a producer with N == K leaves them, W the weight with the norm's gamma multiplied in (W'[n,k] = gamma_k W[n,k], rounded to
+ *     bf16), ln_colsum[n] = sum_k W'[n,k] (fp32; LayerNorm only), ln_bias[n] = b_n + sum_k beta_k W[n,k] (fp32, may be NULL; it
+ *     replaces `bias`):  y = epilogue(r_m * (x W'^T) - r_m mean_m colsum_n + ln_bias_n),  r_m = rsqrt(var_m + ln_eps).
+ * The row statistics are exact fp32 (the reference rounds the normalised tensor to bf16 first: the folded form differs from it
+ * by that rounding, i.e. it is the more accurate of the two). */
+int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
+                      int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
+                      const uint16_t *scale, const uint16_t *res, int ldr,
+                      float *ln_out, const float *ln_in, int ln_slots, int ln_rms, float ln_eps,
+                      const float *ln_colsum, const float *ln_bias, vllm_stream_t stream);
+
 /* B5: InternRMSNorm / apex FusedRMSNorm (modeling_intern_vit.py:33-58): y = w * bf16(x * rsqrt(mean(x^2)+eps)).
  * Row strides allow the in-place QK-RMSNorm over the q / k column blocks of the qkv buffer (:131-134). */
 int vllm_rmsnorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, uint16_t *y, int ldy,
@@ -313,6 +329,14 @@ typedef struct VllmVitLayer {
     const uint16_t *fc1_w, *fc1_b;       /* [I, C], [I] */
     const uint16_t *fc2_w, *fc2_b;       /* [C, I], [C] */
     const uint16_t *ls2;
+    /* Optional (all NULL = launch the norms): the norms folded into the GEMMs around them (vllm_gemm_bf16_ln; taken for
+     * hidden >= 1024 and >= 1024 tokens).  *_w_ln = the weight with the norm's gamma multiplied in, bf16, same shape;
+     * *_colsum[n] = sum_k w_ln[n, k], fp32 (LayerNorm; NULL for RMSNorm); *_bias_ln[n] = b_n + sum_k beta_k w[n, k], fp32
+     * (NULL = 0).  Prepared once per weight set by the caller (the Python mirrors do it when they pack the parameters). */
+    const uint16_t *qkv_w_ln;
+    const float *qkv_colsum, *qkv_bias_ln;
+    const uint16_t *fc1_w_ln;
+    const float *fc1_colsum, *fc1_bias_ln;
 } VllmVitLayer;
 
 typedef struct VllmVitDesc {

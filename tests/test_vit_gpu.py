@@ -239,6 +239,69 @@ def test_gemm256_stream_k_tail(M, N, K, epi, force):
     assert (ys[0] != y0).float().mean().item() < 0.02
 
 
+@pytest.mark.parametrize("rms", [0, 1])
+@pytest.mark.parametrize("M,C,N,force", [(1154, 1024, 3072, 0x200), (1154, 1024, 4096, 0x300), (700, 960, 1024, 0x200), (2050, 1024, 1024, 0)])
+def test_gemm_folded_norm(M, C, N, force, rms):
+    """LayerNorm / RMSNorm folded into the GEMMs around it (vllm_gemm_bf16_ln): the producer's per-(row, column tile)
+    statistics of the bf16 values it stores; the consumer on un-normalised rows + gamma-scaled weights against the fp64
+    evaluation of the same expression, and against norm -> bf16 -> GEMM (the reference's order) to bf16 accuracy."""
+    torch.manual_seed(M + C + N + rms)
+    L = _lib.lib()
+    eps = 1e-5
+    # ---- producer: h = res + x0 W0^T + b0 (residual epilogue), statistics of h per 256-column tile ----
+    K0 = 256
+    x0 = bf(torch.randn(M, K0, device=DEV))
+    w0 = bf(torch.randn(C, K0, device=DEV) / math.sqrt(K0))
+    b0 = bf(torch.randn(C, device=DEV) + 0.5)
+    res = bf(torch.randn(M, C, device=DEV) * 2.0 + 0.75)
+    res[:, 7] += 40.0                                    # an outlier channel, as residual streams have
+    h = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    nt = (C + 255) // 256
+    stats = torch.full((M, nt, 2), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(L.vllm_gemm_bf16_ln(P(x0), P(w0), P(b0), P(h), M, C, K0, K0, K0, C, 3 | (force if force else 0x200), None, P(res), C,
+                                   P(stats), None, 0, rms, eps, None, None, stream()))
+    hd = h.double()
+    for tcol in range(nt):
+        blk = hd[:, tcol * 256:(tcol + 1) * 256]
+        if rms:
+            torch.testing.assert_close(stats[:, tcol, 0].double(), (blk * blk).sum(1), rtol=2e-6, atol=1e-6)
+        else:
+            torch.testing.assert_close(stats[:, tcol, 0].double(), blk.mean(1), rtol=2e-6, atol=2e-6)
+            torch.testing.assert_close(stats[:, tcol, 1].double(), ((blk - blk.mean(1, keepdim=True)) ** 2).sum(1), rtol=2e-5, atol=1e-5)
+    # ---- consumer: y = act(norm(h) W^T + b) from the un-normalised h ----
+    gamma = bf(1.0 + 0.2 * torch.randn(C, device=DEV))
+    beta = bf(0.1 * torch.randn(C, device=DEV)) if not rms else None
+    w = bf(torch.randn(N, C, device=DEV) / math.sqrt(C))
+    b = bf(torch.randn(N, device=DEV))
+    wf = bf(w.float() * gamma.float()[None, :])                     # W' (bf16)
+    colsum = wf.float().sum(1).contiguous()
+    bias_ln = (b.float() + (w.float() @ beta.float() if beta is not None else 0.0)).contiguous()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    epi = 2
+    _lib.check(L.vllm_gemm_bf16_ln(P(h), P(wf), None, P(y), M, N, C, C, C, N, epi | force, None, None, 0, None, P(stats), nt, rms, eps,
+                                   None if rms else P(colsum), P(bias_ln), stream()))
+    if rms:
+        r = torch.rsqrt((hd * hd).mean(1, keepdim=True) + eps)
+        xhat = hd * r
+    else:
+        mu = hd.mean(1, keepdim=True)
+        r = torch.rsqrt(((hd - mu) ** 2).mean(1, keepdim=True) + eps)
+        xhat = (hd - mu) * r
+    z = xhat @ wf.double().t() + bias_ln.double()
+    mag = xhat.abs() @ wf.double().abs().t() + bias_ln.double().abs()
+    if not rms:   # the folded form subtracts r * mean * colsum from r * acc: its terms are the magnitude the fp32 sums carry
+        mag = mag + (r * mu.abs()) * colsum.double().abs()[None, :] + (r * hd.abs()) @ wf.double().abs().t()
+    zq = z * torch.sigmoid(1.702 * z)
+    ulp_close(y, zq, 1.0, mag, 2.0 ** -16, f"folded norm rms={rms} M{M} C{C} N{N} force={force:#x}")
+    # the reference's order: normalise, round to bf16, multiply by gamma (+ beta), round, GEMM with W
+    if rms:
+        xn = bf(bf(xhat.float()).float() * gamma.float())
+    else:
+        xn = bf(xhat.float() * gamma.float() + beta.float())
+    zr = xn.double() @ w.double().t() + b.double()
+    close(y, zr * torch.sigmoid(1.702 * zr), 2e-2, "folded norm vs norm -> bf16 -> GEMM")
+
+
 def test_gemm_rejects_bad_shapes():
     x = bf(torch.zeros(4, 100, device=DEV))
     with pytest.raises(RuntimeError):
@@ -517,6 +580,54 @@ def test_real_width_encoders_vs_oracle(arch):
     out = model(bf(x).to(DEV), output_hidden_states=True)
     ref, lo = _oracle_errors(fwd, sd, cfgd, x)
     _check_states(out.hidden_states, ref, lo, arch)
+
+
+@pytest.mark.parametrize("arch", ["clip", "internvit"])
+def test_folded_norms_agree_with_launched_norms(arch, monkeypatch):
+    """Round 3: norm1 / norm2 folded into the GEMMs around them (the default at real widths) against the same model with the norms
+    launched (descriptor without the prepared weights): the two differ by the bf16 rounding of the normalised tensor that the
+    folded form does not do -- bf16-level agreement on every hidden state; both are run-to-run identical."""
+    from visionllm_amd import clip_vit as CV, intern_vit as IV
+    torch.manual_seed(5)
+    if arch == "clip":
+        from transformers import CLIPVisionConfig
+        cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=3,
+                    image_size=336, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+        make = lambda: CLIPVisionModel(CLIPVisionConfig(**cfgd))  # noqa: E731
+        n, mod = 2, CV
+    else:
+        cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=3,
+                    image_size=448, patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu", layer_norm_eps=1e-6)
+        make = lambda: InternVisionModel(InternVisionConfig(**cfgd))  # noqa: E731
+        n, mod = 1, IV
+    model = make()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2 and "embedding" not in name:
+                p.normal_(0, 0.02)
+            elif "norm" in name and name.endswith("weight"):
+                p.normal_(1.0, 0.2)
+            elif "norm" in name and name.endswith("bias"):
+                p.normal_(0.0, 0.1)
+            elif name.endswith("ls1") or name.endswith("ls2"):
+                p.fill_(0.1)
+    sd = model.state_dict()
+    x = bf(torch.randn(n, 3, cfgd["image_size"], cfgd["image_size"])).to(DEV)
+    model = model.to(DEV).to(torch.bfloat16)
+    folded = model(x, output_hidden_states=True).hidden_states
+    again = model(x, output_hidden_states=True).hidden_states
+    assert all(torch.equal(a, b) for a, b in zip(folded, again))
+    assert any(int(getattr(l, "qkv_w_ln") or 0) != 0 for l in model._plan.layers), "the folded path was expected to be prepared"
+    monkeypatch.setattr(mod, "norm_folding_applies", lambda *a: False)
+    plain_model = make()
+    plain_model.load_state_dict(sd)
+    plain_model = plain_model.to(DEV).to(torch.bfloat16)
+    plain = plain_model(x, output_hidden_states=True).hidden_states
+    assert all(int(getattr(l, "qkv_w_ln") or 0) == 0 for l in plain_model._plan.layers)
+    assert torch.equal(folded[0], plain[0])
+    for i, (a, b) in enumerate(zip(folded, plain)):
+        rms = ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
+        assert rms <= 6e-3, f"hidden state {i}: relative rms {rms:.4g} between folded and launched norms"
 
 
 @pytest.mark.parametrize("kind,ps", [("linear", False), ("mlp2x_gelu", False), ("internvl_mlp", True), ("mlp2x_gelu", True),

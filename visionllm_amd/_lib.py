@@ -110,7 +110,8 @@ _P = ctypes.c_void_p
 
 class VllmVitLayer(ctypes.Structure):
     _fields_ = [(n, _P) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "q_norm_w", "k_norm_w", "proj_w", "proj_b",
-                                  "ls1", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                  "ls1", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
+                                  "qkv_w_ln", "qkv_colsum", "qkv_bias_ln", "fc1_w_ln", "fc1_colsum", "fc1_bias_ln")]
 
 
 class VllmVitDesc(ctypes.Structure):

@@ -14,7 +14,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .vit_common import (EncoderPlan, _require_bf16_cuda, kpad_for, model_output, padded_patch_weight, run_encoder)
+from .vit_common import (EncoderPlan, _require_bf16_cuda, fold_norm_into_linear, kpad_for, model_output, norm_folding_applies,
+                         padded_patch_weight, run_encoder)
 
 try:
     from transformers import CLIPVisionConfig  # noqa: F401  (the reference passes this very config class)
@@ -122,11 +123,19 @@ class CLIPVisionModel(nn.Module):
             qkv_w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().contiguous()
             qkv_b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().contiguous()
             plan.keep += [qkv_w, qkv_b]
+            fold = {}
+            if norm_folding_applies(cfg.hidden_size, cfg.intermediate_size):
+                q_ln, q_cs, q_b = fold_norm_into_linear(qkv_w, qkv_b, lyr.layer_norm1.weight, lyr.layer_norm1.bias, True)
+                f_ln, f_cs, f_b = fold_norm_into_linear(lyr.mlp.fc1.weight, lyr.mlp.fc1.bias, lyr.layer_norm2.weight,
+                                                        lyr.layer_norm2.bias, True)
+                plan.keep += [q_ln, q_cs, q_b, f_ln, f_cs, f_b]
+                fold = dict(qkv_w_ln=P(q_ln), qkv_colsum=P(q_cs), qkv_bias_ln=P(q_b), fc1_w_ln=P(f_ln), fc1_colsum=P(f_cs),
+                            fc1_bias_ln=P(f_b))
             layers[i] = _lib.VllmVitLayer(
                 norm1_w=P(lyr.layer_norm1.weight), norm1_b=P(lyr.layer_norm1.bias), qkv_w=P(qkv_w), qkv_b=P(qkv_b),
                 q_norm_w=None, k_norm_w=None, proj_w=P(a.out_proj.weight), proj_b=P(a.out_proj.bias), ls1=None,
                 norm2_w=P(lyr.layer_norm2.weight), norm2_b=P(lyr.layer_norm2.bias), fc1_w=P(lyr.mlp.fc1.weight),
-                fc1_b=P(lyr.mlp.fc1.bias), fc2_w=P(lyr.mlp.fc2.weight), fc2_b=P(lyr.mlp.fc2.bias), ls2=None)
+                fc1_b=P(lyr.mlp.fc1.bias), fc2_w=P(lyr.mlp.fc2.weight), fc2_b=P(lyr.mlp.fc2.bias), ls2=None, **fold)
         act = _lib.EPI_QUICK_GELU if getattr(cfg, "hidden_act", "quick_gelu") == "quick_gelu" else _lib.EPI_GELU
         desc = _lib.VllmVitDesc(
             arch=_lib.ARCH_CLIP, num_layers=L, hidden=cfg.hidden_size, heads=cfg.num_attention_heads,

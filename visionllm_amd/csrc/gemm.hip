@@ -270,6 +270,10 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     }
     if (a.variant == 4) { a.variant = 2; a.variant256 = 5; }   // 8-phase schedule on the 32x32x16 instruction
     VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");
+    if (a.ln_in || a.ln_out) {   // folded norm: only the 8-phase kernel implements it
+        VLLM_REQUIRE(a.variant != 1 && epi != EPI_MSDA, "gemm: a folded norm needs the 8-phase kernel");
+        return gemm256_bf16_launch(epi, a, st);
+    }
     if (a.variant != 1 && (a.variant == 2 || (a.N >= 1024 && a.M >= 1024)))
         return gemm256_bf16_launch(epi, a, st);
     // bf16 epilogues of this kernel: through LDS (0) when 16-byte rows are possible, else straight from the accumulators (1)
@@ -316,6 +320,22 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     if (epilogue & 0x800) a.variant = 4;                         // VLLM_GEMM_FORCE_MF32
     if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }   // VLLM_GEMM_FORCE_192
     else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
+    return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
+}
+
+extern "C" int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y, int M, int N, int K, int ldx,
+                                 int ldw, int ldy, int epilogue, const uint16_t *scale, const uint16_t *res, int ldr, float *ln_out,
+                                 const float *ln_in, int ln_slots, int ln_rms, float ln_eps, const float *ln_colsum,
+                                 const float *ln_bias, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(X && W && Y, "vllm_gemm_bf16_ln: null pointer");
+    GemmArgs a;
+    a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = 0; a.mt = a.nt = 0; a.xP = 0; a.variant = 0; a.variant256 = 0; a.direct_store = gemm_direct_store();
+    if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }
+    else if (((epilogue >> 8) & 3) == 2) { a.variant = 2; a.variant256 = 4; }
+    a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ln_slots; a.ln_cols = K; a.ln_rms = ln_rms; a.ln_eps = ln_eps;
+    a.ln_colsum = ln_colsum; a.ln_bias = ln_bias;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
 }
 

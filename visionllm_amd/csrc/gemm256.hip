@@ -16,6 +16,7 @@
 //     the vmcnt wait + barrier that retire it (RAW) -- /opt/skills/guides/cdna_hip_programming.md section 5.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
 
@@ -56,6 +57,20 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
     }
 }
 
+// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63), in every lane: quad butterfly and two row rotations by DPP, one
+// ds_bpermute for the other row of the half
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xb1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4e>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x124>{});   // row_ror:4
+    v += dpp(v, std::integral_constant<int, 0x128>{});   // row_ror:8
+    return v + __shfl_xor(v, 16);
+}
+
 #define G2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define G2_BARRIER()                      \
     do {                                  \
@@ -76,10 +91,13 @@ __device__ __forceinline__ void issue_half(const uint16_t *__restrict__ src, int
 // (2/3 of the matrix peak, tools/probes/mfma_rate.hip), the 32x32x16 one every 32 cycles for twice the flops.  A wave's
 // quadrant piece is then two 32(m) x 32(n) blocks, 8 MFMAs per phase; fragments are 16 bytes of one row per lane
 // (row = lane & 31, k half = lane >> 5), the k16 step ks selects chunk pair 2ks, 2ks+1 -> byte offset ^ (ks << 5).
-template <int EPI, int MT, bool MF32 = false>
+// LNC: the consumer side of a folded norm (GemmArgs::ln_in) -- its own instantiation: the epilogue's extra operands must not
+// cost the plain kernels a register
+template <int EPI, int MT, bool MF32 = false, bool LNC = false>
 __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmArgs a0_)
 {
     static_assert(!MF32 || MT == 4, "32x32x16 path: 256-row tiles only");
+    static_assert(!LNC || !MF32, "folded norm: 16x16x32 schedule only");
     typedef float f32x16_t __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     auto k_of = [&](int t) { return (kbeg + (t < nk ? t : nk - 1)) * G2_BK; };   // clamped: tail refills are harmless
     auto issue_A = [&](int half, int stage, int t) {
         issue_half<4 * MT, MF32>(a.X, a.ldx, m0 + half * (32 * MT), a.M, k_of(t), smem + stage * G2_STAGE + (half ? OFF_A1 : OFF_A0),
-                           wave, lane, a.xP);
+                           wave, lane, LNC ? 0 : a.xP);   // (a folded norm never feeds the CLS-skipping loader: no division to carry)
     };
     auto issue_B = [&](int half, int stage, int t) {
         issue_half<16, MF32>(a.W, a.ldw, n0 + half * 128, a.N, k_of(t), smem + stage * G2_STAGE + (half ? OFF_B1 : OFF_B0), wave,
@@ -336,6 +354,28 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
 
+    // Folded norm, consumer side (LNC; rows of exactly four column tiles, i.e. hidden size 1024): the tile's 256 x 4 x {mean, M2}
+    // (8 KiB, contiguous) and its 256 column sums / fp32 biases come in by LDS-DMA, IN FRONT of the prologue's DMA (older than all
+    // of it: the counted vmcnt waits retire them first, no register is held, no wait of their own), into LDS behind the ring and the
+    // epilogue's output tile; in front of the epilogue's first barrier 256 threads turn the statistics into {r, -r * mean} per
+    // row (Chan's update in a fixed order: exact block means, no cancellation).
+    constexpr int LN_TAB = 256 * 528, LN_CS = LN_TAB + 2048, LN_RAW = LN_TAB + 4096;   // byte offsets in LDS
+    if (LNC && finishing) {
+        {   // wave w: rows 32 w .. 32 w + 31 (two lanes per row, 16 bytes each)
+            int row = m0 + wave * 32 + (lane >> 1);
+            row = row < a.M ? row : a.M - 1;
+            const float *src = a.ln_in + (size_t)row * 8 + (lane & 1) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + LN_RAW + wave * 1024), 16, 0, 0);
+        }
+        if (wave < 2) {   // 256 floats = one 1 KiB instruction each: wave 0 the column sums, wave 1 the biases (a missing vector: zeros below)
+            const float *vec = wave == 0 ? a.ln_colsum : a.ln_bias;
+            int nn = n0 + lane * 4;
+            nn = nn + 4 <= a.N ? nn : a.N - 4;
+            if (vec) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vec + nn),
+                                                      (__attribute__((address_space(3))) void *)(smem + LN_CS + wave * 1024), 16, 0, 0);
+        }
+    }
     // ---- prologue: tile 0 complete in stage 0; tile 1's A0, B1, A1 in flight in stage 1 ----
     issue_A(0, 0, 0); issue_B(0, 0, 0); issue_B(1, 0, 0); issue_A(1, 0, 0);
     issue_A(0, 1, 1); issue_B(1, 1, 1); issue_A(1, 1, 1);
@@ -524,7 +564,34 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
     constexpr int OPITCH = 528;
     const bool via_lds = !a.direct_store && EPI != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
     if (via_lds) {
+        if (LNC) {   // the row table of the folded norm, from the statistics that came in with the prologue (here, not there: the
+                     // prologue has no register to spare, and a spill reload between its DMA issues drains them -- 5 K ticks)
+            if (tid_l < BM_) {
+                const float2_t *sp = reinterpret_cast<const float2_t *>(smem + LN_RAW) + tid_l * 4;
+                float r_, nrm_;
+                if (a.ln_rms) {
+                    const float ss = (sp[0].x + sp[1].x) + (sp[2].x + sp[3].x);
+                    r_ = __builtin_amdgcn_rsqf(fmaf(ss, a.ln_inv_cols, a.ln_eps));
+                    nrm_ = 0.f;
+                } else {
+                    float mean = sp[0].x, m2 = sp[0].y;   // (the launcher's constants: ln_cw[0] = 1, ln_cc[0] = 0)
+#pragma unroll
+                    for (int sidx = 1; sidx < 4; ++sidx) {
+                        const float2_t st_ = sp[sidx];
+                        const float dlt = st_.x - mean;
+                        mean = fmaf(dlt, a.ln_cw[sidx], mean);
+                        m2 += fmaf(dlt * dlt, a.ln_cc[sidx], st_.y);
+                    }
+                    r_ = __builtin_amdgcn_rsqf(fmaf(m2, a.ln_inv_cols, a.ln_eps));
+                    nrm_ = -r_ * mean;
+                }
+                reinterpret_cast<float2_t *>(smem + LN_TAB)[tid_l] = (float2_t){r_, nrm_};
+            }
+            if (tid_l < 2 * G2_BN && !(tid_l < G2_BN ? a.ln_colsum : a.ln_bias)) reinterpret_cast<float *>(smem + LN_CS)[tid_l] = 0.f;
+        }
         __builtin_amdgcn_s_barrier();   // every wave is out of the main loop: no fragment read of the ring is pending
+        const float2_t *ln_tab = reinterpret_cast<const float2_t *>(smem + 256 * OPITCH);               // (= LN_TAB, just built)
+        const float *ln_cs = reinterpret_cast<const float *>(smem + 256 * OPITCH + 2048), *ln_bs = ln_cs + G2_BN;
         if constexpr (MF32) {
             // accumulator register 4g + e of block jb: feature wc*32 + 8g + 4hi + e, token wr*64 + jb*32 + l31
 #pragma unroll
@@ -551,6 +618,13 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 }
             }
         } else {
+        float2_t rn[LNC ? 2 : 1][LNC ? MT : 1];   // folded norm: {r, -r mean} of this lane's 2 x MT rows (the fragment registers are free by now)
+        if constexpr (LNC) {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) rn[qi][j] = ln_tab[qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int qi = q >> 1, qj = q & 1;
@@ -559,13 +633,25 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
                 const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;
                 const int n = n0 + nl;
                 const bool nok = n < a.N;
-                const EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
+                EpiCols cols = epi_cols<EPI>(a, nok ? n : 0);
+                f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+                if (LNC) {   // folded norm: fp32 bias' and column sums of the gamma-scaled weight (staged in the prologue)
+                    const f32x4_t b4 = *reinterpret_cast<const f32x4_t *>(ln_bs + nl);
+                    cols.bia[0] = b4[0]; cols.bia[1] = b4[1]; cols.bia[2] = b4[2]; cols.bia[3] = b4[3];
+                    csum = *reinterpret_cast<const f32x4_t *>(ln_cs + nl);
+                }
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int ml = qi * (32 * MT) + wr * (16 * MT) + j * 16 + fr;
                     const int m = m0 + ml;
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (nok && m < a.M) epi_value<EPI>(a, m, n, acc[q][i][j], cols, v);
+                    if (nok && m < a.M) {
+                        if constexpr (LNC) {
+                            epi_value_folded<EPI>(acc[q][i][j], rn[qi][j].x, rn[qi][j].y, csum, cols, v);
+                        } else {
+                            epi_value<EPI>(a, m, n, acc[q][i][j], cols, v);
+                        }
+                    }
                     uint2_t o;
                     o.x = pack_bf16x2(v[0], v[1]);
                     o.y = pack_bf16x2(v[2], v[3]);
@@ -579,9 +665,38 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
 #pragma unroll 4
         for (int p = 0; p < BM_ / 16; ++p) {
             const int ml = p * 16 + (t >> 5), m = m0 + ml, n = n0 + c8;
-            if (m < a.M && n < a.N) {
-                const uint4_t o = *reinterpret_cast<const uint4_t *>(smem + ml * OPITCH + c8 * 2);
+            const bool live = m < a.M && n < a.N;
+            uint4_t o = {0, 0, 0, 0};
+            if (live) {
+                o = *reinterpret_cast<const uint4_t *>(smem + ml * OPITCH + c8 * 2);
                 *reinterpret_cast<uint4_t *>(a.Y + epi_out_row<EPI>(a, m) * a.ldy + n) = o;
+            }
+            if (a.ln_out) {
+                // folded norm, producer side: statistics of the 256 (or fewer: last column tile) bf16 values of this row that were just
+                // stored -- a row is the 32 lanes of a half wave: mean, then the centred second moment (two passes over registers)
+                const uint32_t u[4] = {o.x, o.y, o.z, o.w};
+                float x_[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) { x_[2 * k2] = bf16lo_to_f32(u[k2]); x_[2 * k2 + 1] = bf16hi_to_f32(u[k2]); }
+                const float nb = (float)min(G2_BN, a.N - n0);
+                float s0, s1;
+                if (a.ln_rms) {
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) q2 = fmaf(x_[k2], x_[k2], q2);
+                    s0 = half_wave_sum(q2); s1 = 0.f;
+                } else {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) sum += x_[k2];
+                    s0 = half_wave_sum(sum) / nb;
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) { const float d = live ? x_[k2] - s0 : 0.f; q2 = fmaf(d, d, q2); }
+                    s1 = half_wave_sum(q2);
+                }
+                if ((t & 31) == 0 && m < a.M)
+                    *reinterpret_cast<float2_t *>(a.ln_out + ((size_t)m * a.nt + tn_idx) * 2) = (float2_t){s0, s1};
             }
         }
         __syncthreads();   // (a second segment's prologue overwrites the ring)
@@ -662,6 +777,25 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                   ? prop.multiProcessorCount : 256;
     }
     a.nt = ceil_div(a.N, G2_BN);
+    if (a.ln_in || a.ln_out) {   // folded norm: the row-wise LDS epilogue is where it lives
+        VLLM_REQUIRE(epi != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && aligned16(a.Y) && a.variant256 != 5,
+                     "gemm256: a folded norm needs the bf16 row-wise epilogue (N, ldy multiples of 8, 16-byte aligned Y, not the 32x32x16 variant)");
+        VLLM_REQUIRE(!a.ln_in || (a.ln_slots == 4 && aligned16(a.ln_in) && a.ln_cols == a.K && (a.ln_rms || a.ln_colsum) &&
+                                  (!a.ln_colsum || aligned16(a.ln_colsum)) && (!a.ln_bias || aligned16(a.ln_bias)) && (a.N & 3) == 0),
+                     "gemm256: folded norm, consumer: statistics of K-element rows in FOUR column tiles (768 < K <= 1024), column sums (LayerNorm), 16-byte aligned fp32 vectors");
+        VLLM_REQUIRE(!a.ln_out || (reinterpret_cast<uintptr_t>(a.ln_out) & 7u) == 0, "gemm256: folded norm, producer: misaligned statistics buffer");
+        a.direct_store = 0;
+        if (a.ln_in) {
+            float cnt = 0.f;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const float nb = (float)std::min(G2_BN, a.ln_cols - sidx * G2_BN), tot = cnt + nb;
+                a.ln_cw[sidx] = nb / tot;
+                a.ln_cc[sidx] = cnt * nb / tot;
+                cnt = tot;
+            }
+            a.ln_inv_cols = 1.f / cnt;
+        }
+    }
     a.res_init = (epi == EPI_RESIDUAL && a.variant256 != 5 && !res_init_disabled() && a.N % 8 == 0 && a.N >= 8 &&
                   a.ldr % 8 == 0 && aligned16(a.res)) ? 1 : 0;
     { static const int pf = [] { const char *e = getenv("VLLM_GEMM_PROF"); return e ? atoi(e) : 0; }(); a.prof = pf; }
@@ -736,9 +870,13 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     // not add to it
     if (a.direct_store == 2) a.direct_store = 0;
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
-    const size_t lds = 256 * 528;      // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB)
+    const size_t lds = 256 * 528 + 4096 + 8192;   // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB); behind it 256 x {r, -r mean}, 256 column sums, 256 biases and the 8 KiB of raw statistics of a folded norm
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
+#define SETATTR_LN(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        SETATTR_LN(EPI_BIAS); SETATTR_LN(EPI_GELU); SETATTR_LN(EPI_QUICK_GELU);
+#undef SETATTR_LN
 #define SETATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<E, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -748,6 +886,15 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 #define L(E) do { if (mf32) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4, true>), grid, block, lds, st, a); \
                   else if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4>), grid, block, lds, st, a); \
                   else VLLM_LAUNCH((gemm256_bf16_kernel<E, 3>), grid, block, lds, st, a); } while (0)
+    if (a.ln_in) {   // consumer of a folded norm: its own instantiations (bias / GELU / quick-GELU epilogues)
+        VLLM_REQUIRE(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU, "gemm256: a folded norm feeds a bias / GELU / quick-GELU epilogue");
+#define LLN(E) do { if (MT == 4) VLLM_LAUNCH((gemm256_bf16_kernel<E, 4, false, true>), grid, block, lds, st, a); \
+                    else VLLM_LAUNCH((gemm256_bf16_kernel<E, 3, false, true>), grid, block, lds, st, a); } while (0)
+        if (epi == EPI_BIAS) LLN(EPI_BIAS); else if (epi == EPI_GELU) LLN(EPI_GELU); else LLN(EPI_QUICK_GELU);
+#undef LLN
+        VLLM_CHECK_LAUNCH("gemm256_bf16_kernel (folded norm)");
+        return VLLM_OK;
+    }
     switch (epi) {
     case EPI_BIAS: L(EPI_BIAS); break;
     case EPI_GELU: L(EPI_GELU); break;

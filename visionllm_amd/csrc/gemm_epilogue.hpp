@@ -82,6 +82,26 @@ __device__ __forceinline__ void epi_value(const GemmArgs &a, int m, int n, const
     }
 }
 
+// The same for the consumer of a folded norm (bias / GELU / quick-GELU): x = r_m acc - r_m mean_m colsum_n + bias'_n as two
+// fmas per element, rn = {r_m, -r_m mean_m}.
+template <int EPI, typename ACC4, typename F4>
+__device__ __forceinline__ void epi_value_folded(const ACC4 &acc, float rn_x, float rn_y, const F4 &colsum, const EpiCols &c, float (&v)[4])
+{
+    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU, "a folded norm feeds a bias / GELU / quick-GELU epilogue");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float x = fmaf(rn_x, acc[r], fmaf(rn_y, colsum[r], c.bia[r]));
+        if (EPI == EPI_GELU) {
+            v[r] = gelu_erf(x);
+        } else if (EPI == EPI_QUICK_GELU) {
+            constexpr float kq = -1.702f * 1.4426950408889634f;
+            v[r] = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * kq));
+        } else {
+            v[r] = x;
+        }
+    }
+}
+
 // Output row of GEMM row m (the patch-embedding epilogue scatters past the CLS slot of every image).
 template <int EPI>
 __device__ __forceinline__ size_t epi_out_row(const GemmArgs &a, int m)

@@ -46,6 +46,23 @@ struct GemmArgs {
     int sk_tiles = 0;       // tiles (the last ones of the dense order) whose K iterations are spread evenly over sk_blocks blocks
     int sk_dp = 0;          // tiles in front of them: one block each, as without stream-K
     int sk_blocks = 0;
+    // LayerNorm / RMSNorm folded into the GEMMs around it (8-phase kernel, row-wise LDS epilogue; vit.cpp):
+    //   the PRODUCER of the normalised tensor (proj / fc2 + residual) leaves, per output row and 256-column tile, {mean, M2} (or
+    //   {sum of squares, -} for RMSNorm) of the bf16 values it stores: ln_out [M][nt][2];
+    //   the CONSUMER (qkv / fc1) reads the UN-normalised rows as its X operand, multiplies with weights that carry the norm's
+    //   gamma, and applies the row statistics in its epilogue:  y = act(r_m * acc + (-r_m * mean_m) * colsum_n + bias'_n).
+    float *ln_out = nullptr;
+    const float *ln_in = nullptr;
+    int ln_slots = 0;               // column tiles per row of ln_in
+    int ln_cols = 0;                // elements per normalised row (the producer's N)
+    int ln_rms = 0;                 // 1: RMSNorm (second moment about zero, no shift)
+    float ln_eps = 0.f;
+    const float *ln_colsum = nullptr;   // consumer: s_n = sum_k W'[n, k] (LayerNorm), fp32 [N]
+    const float *ln_bias = nullptr;     // consumer: bias'_n = b_n + sum_k beta_k W[n, k] (fp32 [N]; NULL = 0); replaces `bias`
+    // consumer, filled by the launcher from ln_cols (uniform float arithmetic in the kernel would sit in VECTOR registers across
+    // the main loop: that is what spilled): Chan's update of the running {mean, M2} with column tile s is
+    //   mean += (mean_s - mean) * ln_cw[s];  M2 += M2_s + (mean_s - mean)^2 * ln_cc[s];   ln_inv_cols = 1 / ln_cols
+    float ln_cw[4] = {0.f, 0.f, 0.f, 0.f}, ln_cc[4] = {0.f, 0.f, 0.f, 0.f}, ln_inv_cols = 0.f;
     unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
                                            // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
 };

@@ -4,6 +4,7 @@
 // vllm_vit_forward replaces the Python layer loop of InternVisionEncoder.forward
 // (VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:253-270) and of HF CLIPEncoder;
 // vllm_bridge_forward replaces select + pixel_shuffle + vl_bridge (visionllmv2/model/modeling_visionllmv2.py:569-579).
+#include <stdlib.h>
 #include "kernels.hpp"
 
 using namespace vllm;
@@ -12,7 +13,7 @@ namespace {
 inline long align256(long x) { return (x + 255) & ~255L; }
 
 struct VitWs {
-    long xn, qkv, ao, hmid, mid, col, h0, h1, sk, total;
+    long xn, qkv, ao, hmid, mid, col, h0, h1, sk, ln, total;
 };
 
 VitWs vit_ws_layout(const VllmVitDesc *d, int n)
@@ -30,6 +31,7 @@ VitWs vit_ws_layout(const VllmVitDesc *d, int n)
     w.h0 = take(M * d->hidden * 2);   // ping-pong hidden states for entries the caller does not want
     w.h1 = take(M * d->hidden * 2);
     w.sk = take(SK_SCRATCH_BYTES);    // stream-K tail of the GEMMs (kernels.hpp)
+    w.ln = take(2 * M * ((d->hidden + 255) / 256) * 2 * 4);   // folded norms: {mean, M2} per (row, 256-column tile), two buffers
     w.total = off;
     return w;
 }
@@ -102,16 +104,51 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         TRY(norm_bf16_launch(false, emb, C, d->pre_ln_w, d->pre_ln_b, state(0), C, M, C, d->eps, st));
     }
 
+    // Folded norms (round 3): between a residual GEMM and the qkv / fc1 GEMM behind it the norm is not launched -- the residual
+    // GEMM's epilogue leaves per-row statistics of what it stores (ln_a: for norm1 of the next layer, ln_b: for norm2 of this one),
+    // the consumer multiplies the un-normalised rows with gamma-scaled weights and applies the statistics in its epilogue
+    // (GemmArgs::ln_*; 46 of the 49 norm launches of a ViT-L forward pass disappear).  Needs the prepared weights in the
+    // descriptor and shapes that take the 8-phase GEMM; VLLM_LN_FOLD=0 switches it off (A/B).
+    static const int fold_off = [] { const char *e = getenv("VLLM_LN_FOLD"); return e && e[0] == '0' ? 1 : 0; }();
+    const int ntC = (C + 255) / 256;
+    float *ln_a = (float *)(ws + w.ln), *ln_b = ln_a + (size_t)M * ntC * 2;
+    // (the consumer stages the statistics of rows of exactly four 256-column tiles: hidden size 1024 -- ViT-L, InternViT-300M)
+    const bool shapes_fold = !fold_off && M >= 1024 && C == 1024 && I >= 1024 && I % 8 == 0;
+    auto gemm_ln = [&](int epi, const uint16_t *X, int ldx, const uint16_t *W, int ldw, const uint16_t *bias, uint16_t *Y, int ldy, int N,
+                       int K, const uint16_t *scale, const uint16_t *res, int ldr, float *ln_out, const float *ln_in,
+                       const float *colsum, const float *bias_ln) {
+        GemmArgs a;
+        gemm_set_scratch(a, sk, SK_SCRATCH_BYTES);
+        a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
+        a.M = (int)M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = 0; a.mt = a.nt = 0; a.xP = 0;
+        a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
+        if (a.variant == 1) a.variant = 0;   // (a forced 128x128 kernel cannot fold)
+        a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ntC; a.ln_cols = C; a.ln_rms = clip ? 0 : 1; a.ln_eps = d->eps;
+        a.ln_colsum = colsum; a.ln_bias = bias_ln;
+        return gemm_bf16_launch(epi, a, st);
+    };
+    auto folds = [&](int i) {   // layer i has the prepared weights
+        return shapes_fold && i >= 0 && i < d->num_layers && d->layers[i].qkv_w_ln && d->layers[i].fc1_w_ln &&
+               (!clip || (d->layers[i].qkv_colsum && d->layers[i].fc1_colsum));
+    };
+
     for (int i = 0; i < d->num_layers; ++i) {
         const VllmVitLayer &L = d->layers[i];
         const uint16_t *h = state(i);
         uint16_t *hout = state(i + 1);
         VLLM_REQUIRE(L.norm1_w && L.qkv_w && L.proj_w && L.norm2_w && L.fc1_w && L.fc2_w, "vit: layer %d parameters missing", i);
+        const bool fold = folds(i);
+        const bool stats1 = fold && i > 0 && folds(i - 1);   // the previous layer's fc2 left norm1's statistics in ln_a
         // attention block
-        prof_mark(PT_NORM, st);
-        TRY(norm_bf16_launch(!clip, h, C, L.norm1_w, L.norm1_b, xn, C, M, C, d->eps, st));
-        prof_mark(PT_QKV, st);
-        TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
+        if (stats1) {
+            prof_mark(PT_QKV, st);
+            TRY(gemm_ln(EPI_BIAS, h, C, L.qkv_w_ln, C, nullptr, qkv, 3 * C, 3 * C, C, nullptr, nullptr, 0, nullptr, ln_a, L.qkv_colsum, L.qkv_bias_ln));
+        } else {
+            prof_mark(PT_NORM, st);
+            TRY(norm_bf16_launch(!clip, h, C, L.norm1_w, L.norm1_b, xn, C, M, C, d->eps, st));
+            prof_mark(PT_QKV, st);
+            TRY(gemm(st, EPI_BIAS, xn, C, L.qkv_w, C, L.qkv_b, qkv, 3 * C, (int)M, 3 * C, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
+        }
         if (L.q_norm_w || L.k_norm_w) prof_mark(PT_QKNORM, st);
         if (L.q_norm_w && L.k_norm_w) {   // both (InternViT-6B): one launch over the [M, 2C] slab, q / k weight per column group
             TRY(norm_bf16_launch(true, qkv, 3 * C, L.q_norm_w, nullptr, qkv, 3 * C, M, C, d->eps, st, L.k_norm_w, 2));
@@ -131,14 +168,21 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
             TRY(attn_fwd_launch(a, D, st));
         }
         prof_mark(PT_PROJ, st);
-        TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C, 0, 0, sk, SK_SCRATCH_BYTES));
+        if (fold) TRY(gemm_ln(EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, C, C, L.ls1, h, C, ln_b, nullptr, nullptr, nullptr));
+        else TRY(gemm(st, EPI_RESIDUAL, ao, C, L.proj_w, C, L.proj_b, hmid, C, (int)M, C, C, L.ls1, h, C, 0, 0, sk, SK_SCRATCH_BYTES));
         // MLP block
-        prof_mark(PT_NORM, st);
-        TRY(norm_bf16_launch(!clip, hmid, C, L.norm2_w, L.norm2_b, xn, C, M, C, d->eps, st));
-        prof_mark(PT_FC1, st);
-        TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
+        if (fold) {
+            prof_mark(PT_FC1, st);
+            TRY(gemm_ln(d->act, hmid, C, L.fc1_w_ln, C, nullptr, mid, I, I, C, nullptr, nullptr, 0, nullptr, ln_b, L.fc1_colsum, L.fc1_bias_ln));
+        } else {
+            prof_mark(PT_NORM, st);
+            TRY(norm_bf16_launch(!clip, hmid, C, L.norm2_w, L.norm2_b, xn, C, M, C, d->eps, st));
+            prof_mark(PT_FC1, st);
+            TRY(gemm(st, d->act, xn, C, L.fc1_w, C, L.fc1_b, mid, I, (int)M, I, C, nullptr, nullptr, 0, 0, 0, sk, SK_SCRATCH_BYTES));
+        }
         prof_mark(PT_FC2, st);
-        TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C, 0, 0, sk, SK_SCRATCH_BYTES));
+        if (fold && folds(i + 1)) TRY(gemm_ln(EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, C, I, L.ls2, hmid, C, ln_a, nullptr, nullptr, nullptr));
+        else TRY(gemm(st, EPI_RESIDUAL, mid, I, L.fc2_w, I, L.fc2_b, hout, C, (int)M, C, I, L.ls2, hmid, C, 0, 0, sk, SK_SCRATCH_BYTES));
     }
     prof_mark(PT_END, st);
     return VLLM_OK;

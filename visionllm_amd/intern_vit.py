@@ -15,7 +15,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .vit_common import (EncoderPlan, _require_bf16_cuda, kpad_for, model_output, padded_patch_weight, run_encoder)
+from .vit_common import (EncoderPlan, _require_bf16_cuda, fold_norm_into_linear, kpad_for, model_output, norm_folding_applies,
+                         padded_patch_weight, run_encoder)
 
 try:
     from transformers.configuration_utils import PretrainedConfig as _ConfigBase
@@ -188,13 +189,20 @@ class InternVisionModel(nn.Module):
         P = _lib.ptr
         for i, lyr in enumerate(self.encoder.layers):
             a = lyr.attn
+            fold = {}
+            if norm_folding_applies(cfg.hidden_size, cfg.intermediate_size):
+                q_ln, _, q_b = fold_norm_into_linear(a.qkv.weight, a.qkv.bias, lyr.norm1.weight, None, False)
+                f_ln, _, f_b = fold_norm_into_linear(lyr.mlp.fc1.weight, lyr.mlp.fc1.bias, lyr.norm2.weight, None, False)
+                plan.keep += [q_ln, q_b, f_ln, f_b]
+                fold = dict(qkv_w_ln=P(q_ln), qkv_colsum=None, qkv_bias_ln=P(q_b) if q_b is not None else None, fc1_w_ln=P(f_ln),
+                            fc1_colsum=None, fc1_bias_ln=P(f_b) if f_b is not None else None)
             layers[i] = _lib.VllmVitLayer(
                 norm1_w=P(lyr.norm1.weight), norm1_b=None, qkv_w=P(a.qkv.weight), qkv_b=P(a.qkv.bias),
                 q_norm_w=P(a.q_norm.weight) if a.qk_normalization else None,
                 k_norm_w=P(a.k_norm.weight) if a.qk_normalization else None,
                 proj_w=P(a.proj.weight), proj_b=P(a.proj.bias), ls1=P(lyr.ls1), norm2_w=P(lyr.norm2.weight),
                 norm2_b=None, fc1_w=P(lyr.mlp.fc1.weight), fc1_b=P(lyr.mlp.fc1.bias), fc2_w=P(lyr.mlp.fc2.weight),
-                fc2_b=P(lyr.mlp.fc2.bias), ls2=P(lyr.ls2))
+                fc2_b=P(lyr.mlp.fc2.bias), ls2=P(lyr.ls2), **fold)
         desc = _lib.VllmVitDesc(
             arch=_lib.ARCH_INTERNVIT, num_layers=L, hidden=cfg.hidden_size, heads=cfg.num_attention_heads,
             inter=cfg.intermediate_size, patch=cfg.patch_size,

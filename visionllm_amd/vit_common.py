@@ -38,6 +38,30 @@ def padded_patch_weight(conv_weight, kpad):
     return out
 
 
+def fold_norm_into_linear(w, b, gamma, beta, layernorm):
+    """Operands of a linear layer with the norm in front of it folded in (vllm_gemm_bf16_ln, consumer side):
+        linear(norm(x)) = r (x W'^T) - r mean colsum + bias'      W' = W diag(gamma)  (bf16),
+        colsum_n = sum_k W'[n, k]  (fp32, from the ROUNDED W': the mean shift then cancels exactly for the weights in use),
+        bias'_n = b_n + sum_k beta_k W[n, k]  (fp32).
+    RMSNorm (layernorm=False) has no mean and no beta: colsum is None, bias' is b.  -> (w_ln, colsum, bias_ln)"""
+    w32 = w.detach().float()
+    w_ln = (w32 * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    colsum = w_ln.float().sum(1).contiguous() if layernorm else None
+    bias_ln = b.detach().float().clone() if b is not None else None
+    if beta is not None:
+        shift = w32 @ beta.detach().float()
+        bias_ln = shift if bias_ln is None else bias_ln + shift
+    return w_ln, colsum, (bias_ln.contiguous() if bias_ln is not None else None)
+
+
+def norm_folding_applies(hidden_size, intermediate_size):
+    """The encoder folds its norms into the GEMMs around them at hidden size 1024 (ViT-L, InternViT-300M: rows of exactly four
+    256-column tiles, what the consumer GEMM stages; the C side also asks for >= 1024 tokens per call); VLLM_LN_FOLD=0 keeps the
+    norm launches (A/B)."""
+    import os
+    return os.environ.get("VLLM_LN_FOLD", "1") != "0" and hidden_size == 1024 and intermediate_size >= 1024
+
+
 def kpad_for(patch):
     k = 3 * patch * patch
     return (k + 63) // 64 * 64
