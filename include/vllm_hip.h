@@ -235,6 +235,8 @@ int vllm_point_sample_mean_f32(const float *input, const float *coords, const ui
 #define VLLM_GEMM_FORCE_192 0x300   /* 8-phase schedule, 192-row block tile */
 #define VLLM_GEMM_FORCE_4W 0x400    /* 4-wave schedule: 256x256x32 block tile, 128x128 per wave */
 #define VLLM_GEMM_FORCE_MF32 0x800  /* 8-phase schedule, 256-row block tile, v_mfma_f32_32x32x16_bf16 */
+#define VLLM_GEMM_FORCE_TILEWISE 0x1000 /* 8-phase schedule with one workgroup per tile, where the persistent walk over the tiles
+                                        * (qkv / fc1 shapes: bias / GELU / quick-GELU epilogue, N % 256 == 0) would be taken */
 
 /* Y[M,N] = epilogue(X[M,K] @ W[N,K]^T + bias).  Replaces F.linear / nn.Conv2d-as-GEMM on the path
  * (modeling_intern_vit.py:112,124,128,141,172-178; modeling_visionllmv2.py:162-182).
@@ -253,6 +255,7 @@ int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, u
  * vllm_bridge_forward reserve theirs inside their workspace. */
 long vllm_gemm_scratch_bytes(void);
 long vllm_gemm_sk_launches(void);   /* GEMM launches of this process that took the stream-K tail (tests / tuning) */
+long vllm_gemm_persistent_launches(void);   /* GEMM launches of this process that took the persistent 8-phase schedule (tests / tuning) */
 int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
                       int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
                       const uint16_t *scale, const uint16_t *res, int ldr, int P,

@@ -239,8 +239,48 @@ def test_gemm256_stream_k_tail(M, N, K, epi, force):
     assert (ys[0] != y0).float().mean().item() < 0.02
 
 
+@pytest.mark.parametrize("M,N,K,epi,force,pad,bias", [
+    (23080, 3072, 1024, 0, 0, 0, True),        # the ViT-L qkv GEMM at the bench batch (12 column tiles: row-panel order)
+    (23080, 4096, 1024, 2, 0, 0, True),        # fc1 (16 column tiles: column-panel order)
+    (16500, 2048, 512, 1, 0x300, 0, True),     # 192-row tiles, GELU
+    (9000, 2048, 192, 0, 0x200, 64, True),     # odd number of K tiles (the stage parity carries over a tile boundary), strided X / W / Y
+    (70001, 256, 128, 2, 0x200, 0, False),     # one column tile, the shortest K the schedule takes, no bias, ragged last row tile
+    (12345, 1280, 320, 1, 0x300, 8, True),     # 5 column tiles, ragged rows, 192-row tiles, strided
+])
+def test_gemm256_persistent_schedule(M, N, K, epi, force, pad, bias):
+    """Round 3: the qkv / fc1 shapes walk over their tiles inside ONE workgroup per CU (gemm256p.hip: refills cross tile boundaries,
+    stores are not waited for).  Same MFMA sequence from zero accumulators, same epilogue arithmetic as one workgroup per tile
+    (VLLM_GEMM_FORCE_TILEWISE): the two must agree BIT FOR BIT, run to run, with nothing written outside the [M, N] block."""
+    torch.manual_seed(M + N + K)
+    L = _lib.lib()
+    ldx, ldw, ldy = K + pad, K + pad, N + pad
+    x = bf(torch.randn(M, ldx, device=DEV))
+    w = bf(torch.randn(N, ldw, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV)) if bias else None
+    ys = []
+    before = L.vllm_gemm_persistent_launches()
+    for flags in (force, force, force | 0x1000):
+        y = torch.full((M + 3, ldy), 7.0, dtype=torch.bfloat16, device=DEV)     # canary rows and columns around the output
+        _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b) if bias else None, P(y), M, N, K, ldx, ldw, ldy, epi | flags, None, None, 0, 0, stream()))
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert L.vllm_gemm_persistent_launches() - before == 2, "the persistent schedule was not taken"
+    assert torch.equal(ys[0], ys[1]), "persistent schedule: run-to-run difference"
+    assert torch.equal(ys[0], ys[2]), "persistent schedule differs from one workgroup per tile"
+    assert (ys[0][M:] == 7.0).all() and (ys[0][:, N:] == 7.0).all(), "wrote outside the output block"
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).to(DEV)             # first and last row tiles against fp64
+    z = x[rows, :K].double() @ w[:, :K].double().t() + (b.double() if bias else 0.0)
+    mag = x[rows, :K].double().abs() @ w[:, :K].double().abs().t() + (b.double().abs() if bias else 0.0)
+    if epi == 1:
+        z = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))
+    elif epi == 2:
+        z = z * torch.sigmoid(1.702 * z)
+    ulp_close(ys[0][rows, :N], z, 1.0, mag, 2.0 ** -17, f"gemm persistent epi={epi} force={force:#x} M{M} N{N} K{K}")
+
+
 @pytest.mark.parametrize("rms", [0, 1])
-@pytest.mark.parametrize("M,C,N,force", [(1154, 1024, 3072, 0x200), (1154, 1024, 4096, 0x300), (700, 960, 1024, 0x200), (2050, 1024, 1024, 0)])
+@pytest.mark.parametrize("M,C,N,force", [(1154, 1024, 3072, 0x200), (1154, 1024, 4096, 0x300), (700, 960, 1024, 0x200), (2050, 1024, 1024, 0),
+                                         (23080, 1024, 3072, 0), (16448, 1024, 4096, 0x300)])
 def test_gemm_folded_norm(M, C, N, force, rms):
     """LayerNorm / RMSNorm folded into the GEMMs around it (vllm_gemm_bf16_ln): the producer's per-(row, column tile)
     statistics of the bf16 values it stores; the consumer on un-normalised rows + gamma-scaled weights against the fp64
@@ -300,6 +340,11 @@ def test_gemm_folded_norm(M, C, N, force, rms):
         xn = bf(xhat.float() * gamma.float() + beta.float())
     zr = xn.double() @ w.double().t() + b.double()
     close(y, zr * torch.sigmoid(1.702 * zr), 2e-2, "folded norm vs norm -> bf16 -> GEMM")
+    # the persistent schedule (taken when the GEMM has at least as many tiles as the device has CUs) against one workgroup per tile
+    y1 = torch.empty_like(y)
+    _lib.check(L.vllm_gemm_bf16_ln(P(h), P(wf), None, P(y1), M, N, C, C, C, N, epi | force | 0x1000, None, None, 0, None, P(stats), nt, rms, eps,
+                                   None if rms else P(colsum), P(bias_ln), stream()))
+    assert torch.equal(y, y1), "folded norm: persistent schedule differs from one workgroup per tile"
 
 
 def test_gemm_rejects_bad_shapes():

@@ -318,6 +318,7 @@ extern "C" int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;   // VLLM_GEMM_FORCE_* (tests / tuning)
     if (epilogue & 0x800) a.variant = 4;                         // VLLM_GEMM_FORCE_MF32
+    if (epilogue & 0x1000) a.no_persist = 1;                     // VLLM_GEMM_FORCE_TILEWISE
     if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }   // VLLM_GEMM_FORCE_192
     else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
@@ -334,6 +335,7 @@ extern "C" int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uin
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = 0; a.mt = a.nt = 0; a.xP = 0; a.variant = 0; a.variant256 = 0; a.direct_store = gemm_direct_store();
     if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }
     else if (((epilogue >> 8) & 3) == 2) { a.variant = 2; a.variant256 = 4; }
+    if (epilogue & 0x1000) a.no_persist = 1;
     a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ln_slots; a.ln_cols = K; a.ln_rms = ln_rms; a.ln_eps = ln_eps;
     a.ln_colsum = ln_colsum; a.ln_bias = ln_bias;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
@@ -342,6 +344,8 @@ extern "C" int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uin
 extern "C" long vllm_gemm_scratch_bytes(void) { return SK_SCRATCH_BYTES; }
 namespace vllm { long gemm256_sk_launches(); }
 extern "C" long vllm_gemm_sk_launches(void) { return vllm::gemm256_sk_launches(); }
+namespace vllm { long gemm256p_launches(); }
+extern "C" long vllm_gemm_persistent_launches(void) { return vllm::gemm256p_launches(); }
 
 extern "C" int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y, int M, int N,
                                  int K, int ldx, int ldw, int ldy, int epilogue, const uint16_t *scale,
@@ -358,6 +362,7 @@ extern "C" int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uin
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = P; a.mt = a.nt = 0; a.xP = 0; a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
     if ((epilogue >> 8) & 3) a.variant = (epilogue >> 8) & 3;
     if (epilogue & 0x800) a.variant = 4;
+    if (epilogue & 0x1000) a.no_persist = 1;
     if (((epilogue >> 8) & 3) == 3) { a.variant = 2; a.variant256 = 3; }
     else if (((epilogue >> 8) & 3) == 2) a.variant256 = 4;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);

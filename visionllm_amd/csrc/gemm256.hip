@@ -747,6 +747,10 @@ static bool res_init_disabled()
     return v != 0;
 }
 
+bool gemm256p_takes(int epi, const GemmArgs &a, int cus);                                   // gemm256p.hip
+int gemm256p_launch(int epi, int MT, const GemmArgs &a, int cus, hipStream_t st);
+int gemm256p_debug_counters(long *out, int n);
+
 static long g_sk_launches = 0;   // launches that took the stream-K tail (vllm_gemm_sk_launches: tests assert the path they mean to cover ran)
 long gemm256_sk_launches() { return g_sk_launches; }
 
@@ -869,6 +873,9 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     // tiles), level on fc1 / fc2 / proj; splitting the rows into whole rounds + a tail launch was measured too and does
     // not add to it
     if (a.direct_store == 2) a.direct_store = 0;
+    // qkv / fc1 shapes: the persistent schedule (gemm256p.hip) -- the ring is refilled across tile boundaries, stores drain
+    // under the next tile's main loop
+    if (a.sk_tiles == 0 && !mf32 && gemm256p_takes(epi, a, cus)) return gemm256p_launch(epi, MT, a, cus, st);
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
     const size_t lds = 256 * 528 + 4096 + 8192;   // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB); behind it 256 x {r, -r mean}, 256 column sums, 256 biases and the 8 KiB of raw statistics of a folded norm
     static unsigned long long attr_mask = 0;
@@ -919,6 +926,11 @@ int gemm256_debug_counters(long *out, int n)
     for (int i = 0; i < n && i < 8; ++i) out[i] = (long)h[i];
     const unsigned long long z[8] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_g2_prof), z, sizeof(z));
+    if (n >= 12) {   // slots 4-11: the persistent schedule's clock (gemm256p.hip): main-loop ticks, epilogue ticks, tiles, a tile's K tile 0 / 1 / 2 / 3, -
+        long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gemm256p_debug_counters(pp, 8) == VLLM_OK) for (int i = 0; i < 8; ++i) out[4 + i] = pp[i];
+        return 12;
+    }
     return n < 8 ? n : 8;
 }
 

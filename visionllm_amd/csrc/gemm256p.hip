@@ -1,0 +1,430 @@
+// bf16 GEMM, the 8-phase 256x256x64 schedule of gemm256.hip as a PERSISTENT kernel: one workgroup per CU walks over its
+// tiles, and the refill pipeline never drains between them.
+//
+// Why (profiles/r02_gemm256_block_trace.txt, r02_gemm256_phases.txt; K = 1024, the ViT-L qkv / fc1 shapes): of the 30.7 us a
+// CU spends per tile, 22.5 us are the main loop; the rest is the prologue (first K tiles from a cold ring, 1.9 us), the epilogue
+// (output tile through LDS + waiting for the stores, 4.9 - 8.5 us) and the gap until the next workgroup starts (1.3 us).  Here
+//   * the K-tile refills of the last two iterations of a tile fetch the first two K tiles of the block's NEXT tile (same ring,
+//     same counted vmcnt(6) once per K tile): when the last MFMA of a tile retires, the next tile's first K tile is in LDS;
+//   * the epilogue stores straight from the accumulators (buffer stores, 8 bytes per lane, rows beyond M dropped by the
+//     descriptor's range check) and does not wait for them: they drain under the next tile's main loop.  vmcnt counts them
+//     together with the refills; loads return in order among themselves, so "at most 6 outstanding" still means "every refill
+//     but the newest six has landed" -- the wait can only be longer than needed, never shorter;
+//   * operands are addressed through buffer descriptors: a lane's part of a refill address is one 32-bit offset per DMA slot
+//     (4 registers in all), the tile / K-tile part is scalar -- nothing per-lane changes from tile to tile.
+// The per-tile column vectors (bias; for the consumer of a folded norm the column sums, bias' and the rows' statistics) come in
+// by LDS-DMA one tile ahead into double-buffered LDS behind the ring.
+//
+// Scope: bias / GELU / quick-GELU epilogues (the qkv and fc1 linears), N a multiple of 256, no CLS-skipping loader, no
+// stream-K tail; everything else stays on gemm256.hip (the launcher there decides).  VLLM_GEMM_PERSIST=0 switches it off.
+#include "common.hpp"
+#include <stdlib.h>
+#include <type_traits>
+#include "kernels.hpp"
+#include "gemm_epilogue.hpp"
+
+namespace vllm {
+
+namespace {
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int P_BN = 256, P_BK = 64, P_THREADS = 512;
+constexpr int P_HALF = 128 * P_BK * 2;            // 16 KiB half-tile
+constexpr int P_STAGE = 4 * P_HALF;               // A0 A1 B0 B1
+constexpr int P_A0 = 0, P_A1 = P_HALF, P_B0 = 2 * P_HALF, P_B1 = 3 * P_HALF;
+constexpr int P_RING = 2 * P_STAGE;               // 128 KiB
+constexpr int P_TAB = P_RING;                     // folded norm: 256 x {r, -r mean}                        2 KiB
+constexpr int P_COL = P_TAB + 2048;               // 2 x 2 KiB: bias (bf16) | folded norm: colsum[256], bias'[256] (fp32)
+constexpr int P_RAW = P_COL + 2 * 2048;           // folded norm: 2 x 8 KiB of raw statistics (256 rows x 4 x {mean, M2})
+constexpr int P_LDS = P_RAW + 2 * 8192;           // 150 KiB
+
+__device__ unsigned long long g_p_prof[8];        // VLLM_GEMM_PROF: ticks of wave 0: main loops, epilogues, tiles, K tile 0 / 1 / 2 / 3 of a tile
+
+#define P_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define P_BARRIER()                       \
+    do {                                  \
+        __builtin_amdgcn_s_barrier();     \
+        __builtin_amdgcn_sched_barrier(0);\
+    } while (0)
+
+template <int EPI, int MT, bool LNC>
+__global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a)
+{
+    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU, "persistent schedule: bias / GELU / quick-GELU epilogues");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, kq = lane >> 4;
+    const int tid = wave * 64 + lane;
+    const int nk = a.K / P_BK;
+    const int T = a.mt * a.nt, G = gridDim.x;
+    constexpr int BM = 64 * MT, HM = 32 * MT;     // block rows; rows of an A half
+
+    // dense tile order of gemm256.hip (XCD = tile & 7 owns a panel): tile -> first row / column
+    auto coords = [&](int td, int &m0, int &n0) {
+        int tm, tn;
+        if ((a.nt & 7) == 0) {
+            const int xcd = td & 7, s = td >> 3, npx = a.nt >> 3;
+            tn = xcd + 8 * (s % npx);
+            tm = s / npx;
+        } else {
+            const int fullp = (a.mt >> 3) * 8 * a.nt;
+            if (td < fullp) {
+                const int xcd = td & 7, s = td >> 3;
+                tm = xcd + 8 * (s / a.nt);
+                tn = s % a.nt;
+            } else {
+                const int vx = a.mt & 7, e = td - fullp;
+                tm = (a.mt & ~7) + e % vx;
+                tn = e / vx;
+            }
+        }
+        m0 = tm * BM; n0 = tn * P_BN;
+    };
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, (int)(((unsigned)(a.M - 1) * (unsigned)a.ldx + (unsigned)a.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, (int)(((unsigned)(a.N - 1) * (unsigned)a.ldw + (unsigned)a.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, (int)(((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.N) * 2u), 0x00020000);
+
+    // ---- a lane's part of the refill addresses: DMA slot s (0 / 1) of this wave is 8 rows of a half-tile; row r of the half,
+    // 16-byte chunk c = (lane & 7) ^ (r & 7) of its 128 bytes (the source-side swizzle of gemm256.hip) ----
+    unsigned xvo[2], wvo[2];
+    int lslot[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int seg = wave * 2 + s;
+        const int xs = seg < 4 * MT ? seg : 4 * MT - 1;           // (MT = 3: idle slots reload the last real segment)
+        const int r8 = lane >> 3, c = (lane & 7) ^ (r8 & 7);
+        xvo[s] = ((unsigned)(xs * 8 + r8) * (unsigned)a.ldx + (unsigned)c * 8u) * 2u;
+        wvo[s] = ((unsigned)(seg * 8 + r8) * (unsigned)a.ldw + (unsigned)c * 8u) * 2u;
+        lslot[s] = seg * 1024;
+    }
+    // refill of one half-tile: K tile `tt` of the current tile, or (tt >= nk) K tile tt - nk of the next one
+    int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
+    auto issue_A = [&](int half, int stage, int tt) {
+        const bool nx = tt >= nk;
+        const unsigned so = ((unsigned)((nx ? m0n : m0) + half * HM) * (unsigned)a.ldx + (unsigned)((nx ? tt - nk : tt) * P_BK)) * 2u;
+        char *dst = smem + stage * P_STAGE + (half ? P_A1 : P_A0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(dst + lslot[s]), 16, (int)xvo[s], (int)so, 0, 0);
+    };
+    auto issue_B = [&](int half, int stage, int tt) {
+        const bool nx = tt >= nk;
+        const unsigned so = ((unsigned)((nx ? n0n : n0) + half * 128) * (unsigned)a.ldw + (unsigned)((nx ? tt - nk : tt) * P_BK)) * 2u;
+        char *dst = smem + stage * P_STAGE + (half ? P_B1 : P_B0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(dst + lslot[s]), 16, (int)wvo[s], (int)so, 0, 0);
+    };
+    // the column vectors (and, folded norm, the row statistics) of the tile at (mm, nn) into buffer `buf`: waves 0-1 / 0-7
+    auto issue_vectors = [&](int mm, int nn, int buf) {
+        if constexpr (LNC) {
+            {   // wave w: rows 32 w .. 32 w + 31 of the tile, two lanes per row (16 of its 32 bytes each)
+                int row = mm + wave * 32 + (lane >> 1);
+                row = row < a.M ? row : a.M - 1;
+                const float *src = a.ln_in + (size_t)row * 8 + (lane & 1) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + P_RAW + buf * 8192 + wave * 1024), 16, 0, 0);
+            }
+            if (wave < 2) {   // 256 floats = one 1 KiB instruction: wave 0 the column sums, wave 1 the biases (a missing vector stays zero)
+                const float *vec = wave == 0 ? a.ln_colsum : a.ln_bias;
+                if (vec) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vec + nn + lane * 4),
+                                                          (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048 + wave * 1024), 16, 0, 0);
+            }
+        } else {
+            if (wave == 0 && a.bias) {   // 256 bf16 = 512 bytes: the upper 32 lanes re-read the last 16 bytes (harmless, in bounds)
+                const int c8 = lane < 32 ? lane : 31;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.bias + nn + c8 * 8),
+                                                 (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048), 16, 0, 0);
+            }
+        }
+    };
+
+    // per-lane LDS byte offsets of the fragments inside a half-tile (ks = 0 / 1 differ by XOR 4 chunks)
+    int xoff[MT], woff[2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int r = wr * (16 * MT) + t * 16 + fr;
+        xoff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = wc * 32 + t * 16 + fr;
+        woff[t] = r * 128 + ((kq ^ (r & 7)) << 4);
+    }
+    // a lane's part of the output address: row wr * 16 MT + fr of a quadrant piece; after the lane-row exchange of the epilogue
+    // lane row kq holds the 8 features from column {0, 16, 8, 24}[kq] of the wave's 32
+    const unsigned yvo = ((unsigned)(wr * (16 * MT) + fr) * (unsigned)a.ldy + (unsigned)(wc * 32 + (kq & 1) * 16 + (kq >> 1) * 8)) * 2u;
+
+    bf16x8_t wg[2][2], xf[MT][2], wf[2][2];
+    f32x4_t acc[4][2][MT];   // [quadrant q = 2 * (A half) + (B half)][n tile][m tile]
+
+    auto read_x = [&](const char *half) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            xf[t][0] = *reinterpret_cast<const bf16x8_t *>(half + xoff[t]);
+            xf[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (xoff[t] ^ 64));
+        }
+    };
+    auto read_w_into = [&](const char *half, bf16x8_t (&dst)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            dst[t][0] = *reinterpret_cast<const bf16x8_t *>(half + woff[t]);
+            dst[t][1] = *reinterpret_cast<const bf16x8_t *>(half + (woff[t] ^ 64));
+        }
+    };
+    // (FIRST: K tile 0 of a tile starts its accumulators from the instruction's constant zero -- no 128 moves per tile)
+#define P_MMA(Q, WF, FIRST)                                                                                     \
+    do {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                  \
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][ks], xf[j][ks],                \
+                                                                           (FIRST && ks == 0) ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : acc[Q][i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    // ---- block prologue: the vectors of the first tile, its K tile 0 complete in stage 0, K tile 1's A0, B1, A1 in flight ----
+    int tile = blockIdx.x;
+    coords(tile, m0, n0);
+    {
+        const int nxt = tile + G;
+        if (nxt < T) coords(nxt, m0n, n0n); else { m0n = m0; n0n = n0; }
+    }
+    for (int i = tid; i < (P_LDS - P_RING) / 4; i += P_THREADS) reinterpret_cast<unsigned *>(smem + P_RING)[i] = 0u;   // (missing vectors read as zeros)
+    __syncthreads();
+    issue_vectors(m0, n0, 0);
+    issue_A(0, 0, 0); issue_B(0, 0, 0); issue_B(1, 0, 0); issue_A(1, 0, 0);
+    issue_A(0, 1, 1); issue_B(1, 1, 1); issue_A(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    P_BARRIER();
+
+    unsigned pf[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int par = 0;                // stage of the current tile's K tile 0 (K tiles alternate stages across tile boundaries)
+    for (int it = 0;; ++it) {
+        const unsigned t_a = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+        unsigned t_k[4] = {t_a, t_a, t_a, t_a};
+        // Inside a tile group 1 runs one barrier behind group 0 (gemm256.hip: one group's MFMA section over the other's reads);
+        // around the epilogue the groups are level again.  Left staggered, group 1 sits at a barrier through group 0's epilogue
+        // and group 0 through group 1's: the two epilogues ran one after the other (phase clock: the first two K tiles of a
+        // tile took 16.8 K ticks instead of 5.2 K).
+        if (wr == 1) P_BARRIER();
+        auto k_tile = [&](int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int s = (t + par) & 1;
+            const char *st = smem + s * P_STAGE;
+            // phase 1: quadrant (A0,B0); refill B0 of the OTHER stage with K tile t+1
+            read_x(st + P_A0); read_w_into(st + P_B0, wf);
+            issue_B(0, s ^ 1, t + 1);
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(0, wf, FIRST);
+            P_BARRIER();
+            // phase 2: quadrant (A0,B1); refill A0 (this stage) with K tile t+2
+            read_w_into(st + P_B1, wg);
+            issue_A(0, s, t + 2);
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(1, wg, FIRST);
+            P_BARRIER();
+            // phase 3: quadrant (A1,B1); refill B1 with K tile t+2
+            read_x(st + P_A1);
+            issue_B(1, s, t + 2);
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(3, wg, FIRST);
+            P_BARRIER();
+            // phase 4: quadrant (A1,B0); refill A1 with K tile t+2; retire everything but the last 3 half-tiles
+            issue_A(1, s, t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(2, wf, FIRST);
+            P_BARRIER();
+            if (a.prof && t < 4) t_k[t] = (unsigned)__builtin_amdgcn_s_memtime();   // (clock: the first K tiles of a tile, one by one)
+        };
+        k_tile(0, std::true_type{});
+#pragma unroll 1
+        for (int t = 1; t < nk; ++t) k_tile(t, std::false_type{});
+        if (wr == 0) P_BARRIER();   // level again
+        par = (par + nk) & 1;
+        const unsigned t_b = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+
+        // ---- between two tiles: the ring already holds the next tile's K tile 0 (its K tile 1 is in flight) ----
+        const int nxt = tile + G;
+        const bool more = nxt < T;
+        const int buf = it & 1;
+        if (more) issue_vectors(m0n, n0n, buf ^ 1);   // (that buffer was last read in the epilogue before the main loop just finished)
+        if constexpr (LNC) {
+            // the row table {r, -r mean} of this tile from its statistics (Chan's update in a fixed order, constants from the
+            // launcher)
+            if (tid < BM) {
+                // (read with inline ds_read: for a compiler-visible LDS load behind an LDS-DMA the compiler drains vmcnt to 0 --
+                //  here that would wait for the next tile's refills; the statistics landed a whole main loop ago)
+                float2_t sp[4];
+                {
+                    const unsigned addr = (unsigned)(size_t)(smem + P_RAW + buf * 8192 + tid * 32);
+                    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(sp[0]), "=&v"(sp[1]), "=&v"(sp[2]), "=&v"(sp[3]) : "v"(addr) : "memory");
+                }
+                float r_, nrm_;
+                if (a.ln_rms) {
+                    const float ss = (sp[0].x + sp[1].x) + (sp[2].x + sp[3].x);
+                    r_ = __builtin_amdgcn_rsqf(fmaf(ss, a.ln_inv_cols, a.ln_eps));
+                    nrm_ = 0.f;
+                } else {
+                    float mean = sp[0].x, m2 = sp[0].y;
+#pragma unroll
+                    for (int sidx = 1; sidx < 4; ++sidx) {
+                        const float2_t st_ = sp[sidx];
+                        const float dlt = st_.x - mean;
+                        mean = fmaf(dlt, a.ln_cw[sidx], mean);
+                        m2 += fmaf(dlt * dlt, a.ln_cc[sidx], st_.y);
+                    }
+                    r_ = __builtin_amdgcn_rsqf(fmaf(m2, a.ln_inv_cols, a.ln_eps));
+                    nrm_ = -r_ * mean;
+                }
+                reinterpret_cast<float2_t *>(smem + P_TAB)[tid] = (float2_t){r_, nrm_};
+            }
+            P_WAIT_LGKM0(); P_BARRIER();
+        }
+        // ---- epilogue: straight from the accumulators, nothing waits for the stores ----
+        // A lane holds 4 features (8 bytes packed) of row fr in each of the wave's two 16-column n tiles; v_permlane16_swap
+        // exchanges the odd lane rows of the first with the even lane rows of the second, after which a lane owns 8 CONSECUTIVE
+        // features: one 16-byte store per lane, 64 contiguous bytes per output row and instruction (half the instructions and
+        // twice the segment length of the plain accumulator layout -- the stores share the CU's address path with the refills).
+        {
+            const char *colb = smem + P_COL + buf * 2048;
+            float2_t rn[LNC ? 2 : 1][LNC ? MT : 1];
+            if constexpr (LNC) {
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) rn[qi][j] = reinterpret_cast<const float2_t *>(smem + P_TAB)[qi * HM + wr * (16 * MT) + j * 16 + fr];
+            }
+            u32x4_t o_prev = {0u, 0u, 0u, 0u};
+            unsigned so_prev = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qi = q >> 1, qj = q & 1;
+                EpiCols cols[2];
+                f32x4_t csum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;
+                    if constexpr (LNC) {
+                        csum[i] = *reinterpret_cast<const f32x4_t *>(colb + nl * 4);
+                        const f32x4_t b4 = *reinterpret_cast<const f32x4_t *>(colb + 1024 + nl * 4);
+                        cols[i].bia[0] = b4[0]; cols[i].bia[1] = b4[1]; cols[i].bia[2] = b4[2]; cols[i].bia[3] = b4[3];
+                    } else {
+                        const uint2_t b = *reinterpret_cast<const uint2_t *>(colb + nl * 2);
+                        cols[i].bia[0] = bf16lo_to_f32(b.x); cols[i].bia[1] = bf16hi_to_f32(b.x); cols[i].bia[2] = bf16lo_to_f32(b.y); cols[i].bia[3] = bf16hi_to_f32(b.y);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cols[i].scl[r] = 1.f;
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float v[4];
+                        if constexpr (LNC) epi_value_folded<EPI>(acc[q][i][j], rn[qi][j].x, rn[qi][j].y, csum[i], cols[i], v);
+                        else epi_value<EPI>(a, 0, 0, acc[q][i][j], cols[i], v);
+                        pk[i][0] = pack_bf16x2(v[0], v[1]); pk[i][1] = pack_bf16x2(v[2], v[3]);
+                    }
+                    const u32x2_t lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const u32x2_t hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    // the store of a piece goes out one piece LATER (behind the next piece's arithmetic): issued right behind
+                    // the lane-row exchange it picked up stale data in the last lanes of every lane row (rows fr >= 12 wrong,
+                    // run-to-run different) -- the exchange's result is not interlocked against a vector-memory read
+                    if (q + j > 0 && !(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yvo, (int)so_prev, 0);   // (prof bit 1: ablation, no stores)
+                    o_prev = (u32x4_t){lo.x, hi.x, lo.y, hi.y};
+                    so_prev = ((unsigned)(m0 + qi * HM + j * 16) * (unsigned)a.ldy + (unsigned)(n0 + qj * 128)) * 2u;
+                }
+            }
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the same distance for the last piece)
+            if (!(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yvo, (int)so_prev, 0);
+        }
+        if (a.prof) {   // (summed per block, written once at its end: an atomic per tile would sit in front of the next tile's refills)
+            const unsigned t_c = (unsigned)__builtin_amdgcn_s_memtime();
+            pf[0] += t_b - t_a; pf[1] += t_c - t_b; pf[2] += 1u;
+            pf[3] += t_k[0] - t_a; pf[4] += t_k[1] - t_k[0]; pf[5] += t_k[2] - t_k[1]; pf[6] += t_k[3] - t_k[2];
+        }
+        if (!more) break;
+        tile = nxt; m0 = m0n; n0 = n0n;
+        {
+            const int n2 = tile + G;
+            if (n2 < T) coords(n2, m0n, n0n); else { m0n = m0; n0n = n0; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+    if (a.prof && wave == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_p_prof[i], (unsigned long long)pf[i]);
+    }
+}
+
+bool persist_disabled()
+{
+    static const int v = [] { const char *e = getenv("VLLM_GEMM_PERSIST"); return e && e[0] == '0' ? 1 : 0; }();
+    return v != 0;
+}
+
+}  // namespace
+
+// Whether the persistent schedule takes this GEMM (the 8-phase launcher asks after it has chosen MT and found no stream-K tail).
+bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
+{
+    if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
+    if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU)) return false;
+    if (a.ln_out || a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
+    if ((a.N % P_BN) != 0 || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (!al16(a.X) || !al16(a.W) || !al16(a.Y) || (a.bias && !al16(a.bias))) return false;
+    const unsigned long long lim = 1ull << 31;   // byte offsets are 32-bit and must stay clear of the range check's wrap
+    if (((unsigned long long)a.M + 256) * (unsigned long long)a.ldx * 2 >= lim || ((unsigned long long)a.N + 256) * (unsigned long long)a.ldw * 2 >= lim ||
+        ((unsigned long long)a.M + 256) * (unsigned long long)a.ldy * 2 >= lim) return false;
+    if ((long)a.mt * a.nt < cus) return false;   // fewer tiles than CUs: nothing to pipeline across
+    return true;
+}
+
+static long g_p_launches = 0;   // (vllm_gemm_persistent_launches: tests assert the path they mean to cover ran)
+long gemm256p_launches() { return g_p_launches; }
+
+int gemm256p_launch(int epi, int MT, const GemmArgs &a, int cus, hipStream_t st)
+{
+    ++g_p_launches;
+    const long T = (long)a.mt * a.nt;
+    const dim3 grid((unsigned)std::min<long>(T, cus)), block(P_THREADS);
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
+#define SETATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 4, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS)
+        SETATTR(EPI_BIAS, false); SETATTR(EPI_GELU, false); SETATTR(EPI_QUICK_GELU, false);
+        SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true);
+#undef SETATTR
+    }
+#define LAUNCH(E) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true>), grid, block, P_LDS, st, a); \
+                                       else VLLM_LAUNCH((gemm256p_kernel<E, 3, true>), grid, block, P_LDS, st, a); } \
+                       else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false>), grid, block, P_LDS, st, a); \
+                              else VLLM_LAUNCH((gemm256p_kernel<E, 3, false>), grid, block, P_LDS, st, a); } } while (0)
+    if (epi == EPI_BIAS) LAUNCH(EPI_BIAS); else if (epi == EPI_GELU) LAUNCH(EPI_GELU); else LAUNCH(EPI_QUICK_GELU);
+#undef LAUNCH
+    VLLM_CHECK_LAUNCH("gemm256p_kernel");
+    return VLLM_OK;
+}
+
+int gemm256p_debug_counters(long *out, int n)
+{
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p_prof), sizeof(h)) != hipSuccess) return VLLM_ELAUNCH;
+    for (int i = 0; i < n && i < 8; ++i) out[i] = (long)h[i];
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p_prof), z, sizeof(z));
+    return VLLM_OK;
+}
+
+}  // namespace vllm

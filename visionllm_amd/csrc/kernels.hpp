@@ -63,6 +63,7 @@ struct GemmArgs {
     // the main loop: that is what spilled): Chan's update of the running {mean, M2} with column tile s is
     //   mean += (mean_s - mean) * ln_cw[s];  M2 += M2_s + (mean_s - mean)^2 * ln_cc[s];   ln_inv_cols = 1 / ln_cols
     float ln_cw[4] = {0.f, 0.f, 0.f, 0.f}, ln_cc[4] = {0.f, 0.f, 0.f, 0.f}, ln_inv_cols = 0.f;
+    int no_persist = 0;             // 1: one workgroup per tile even where the persistent schedule (gemm256p.hip) would take the GEMM
     unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
                                            // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
 };
