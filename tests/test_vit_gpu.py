@@ -200,7 +200,8 @@ def test_gemm256_stream_k_tail(M, N, K, epi, force):
     scratch, nbytes = _sk_scratch()
     L = _lib.lib()
     args = (P(x), P(w), P(b))
-    tail = (M, N, K, K, K, N, epi | force, P(ls) if (epi == 3 and ls is not None) else None, P(res) if epi == 3 else None, N, 0)
+    # (0x1000 = VLLM_GEMM_FORCE_TILEWISE: where the persistent schedule would take the GEMM, it is asked before the stream-K tail)
+    tail = (M, N, K, K, K, N, epi | force | 0x1000, P(ls) if (epi == 3 and ls is not None) else None, P(res) if epi == 3 else None, N, 0)
     before = L.vllm_gemm_sk_launches()
     ys = []
     for _ in range(3):
@@ -246,6 +247,8 @@ def test_gemm256_stream_k_tail(M, N, K, epi, force):
     (9000, 2048, 192, 0, 0x200, 64, True),     # odd number of K tiles (the stage parity carries over a tile boundary), strided X / W / Y
     (70001, 256, 128, 2, 0x200, 0, False),     # one column tile, the shortest K the schedule takes, no bias, ragged last row tile
     (12345, 1280, 320, 1, 0x300, 8, True),     # 5 column tiles, ragged rows, 192-row tiles, strided
+    (8200, 9600, 640, 0, 0, 0, True),          # InternViT-6B qkv width: 37.5 column tiles (the last one 128 wide)
+    (20000, 1096, 128, 2, 0x200, 16, True),    # last column tile 72 wide, strided
 ])
 def test_gemm256_persistent_schedule(M, N, K, epi, force, pad, bias):
     """Round 3: the qkv / fc1 shapes walk over their tiles inside ONE workgroup per CU (gemm256p.hip: refills cross tile boundaries,
@@ -260,7 +263,7 @@ def test_gemm256_persistent_schedule(M, N, K, epi, force, pad, bias):
     ys = []
     before = L.vllm_gemm_persistent_launches()
     for flags in (force, force, force | 0x1000):
-        y = torch.full((M + 3, ldy), 7.0, dtype=torch.bfloat16, device=DEV)     # canary rows and columns around the output
+        y = torch.full((M + 300, ldy), 7.0, dtype=torch.bfloat16, device=DEV)     # canary rows (a whole tile's worth) and, strided cases, columns
         _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b) if bias else None, P(y), M, N, K, ldx, ldw, ldy, epi | flags, None, None, 0, 0, stream()))
         ys.append(y)
     torch.cuda.synchronize()

@@ -861,6 +861,18 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     if (mf32) MT = 4;
     a.mt = ceil_div(a.M, 64 * MT);
     a.sk_tiles = MT == 3 ? sk3 : sk4;
+    // qkv / fc1 shapes: the persistent schedule (gemm256p.hip) -- the ring is refilled across tile boundaries, stores drain
+    // under the next tile's main loop: ~10 % per tile (tools/gemm_persist_ab.py), more than the stream-K tail recovers, so it
+    // is asked first, with the tile height that needs fewer whole rounds
+    if (!mf32) {
+        auto rounds = [&](int mt_rows) { return (double)ceil_div((long)ceil_div(a.M, 64 * mt_rows) * a.nt, (long)cus) * (mt_rows == 4 ? 100.0 : 87.0); };
+        int pmt = rounds(3) < rounds(4) ? 3 : 4;
+        if (a.variant256 == 3 || a.variant256 == 4) pmt = a.variant256;
+        GemmArgs b = a;
+        b.sk_tiles = 0;
+        b.mt = ceil_div(a.M, 64 * pmt);
+        if (gemm256p_takes(epi, b, cus)) return gemm256p_launch(epi, pmt, b, cus, st);
+    }
     long tiles;
     if (a.sk_tiles > 0) {
         ++g_sk_launches;
@@ -873,9 +885,6 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     // tiles), level on fc1 / fc2 / proj; splitting the rows into whole rounds + a tail launch was measured too and does
     // not add to it
     if (a.direct_store == 2) a.direct_store = 0;
-    // qkv / fc1 shapes: the persistent schedule (gemm256p.hip) -- the ring is refilled across tile boundaries, stores drain
-    // under the next tile's main loop
-    if (a.sk_tiles == 0 && !mf32 && gemm256p_takes(epi, a, cus)) return gemm256p_launch(epi, MT, a, cus, st);
     const dim3 grid((unsigned)tiles), block(G2_THREADS);
     const size_t lds = 256 * 528 + 4096 + 8192;   // 2 stages x 64 KiB of ring; the epilogue re-uses it as a 256 x 528 B output tile (132 KiB); behind it 256 x {r, -r mean}, 256 column sums, 256 biases and the 8 KiB of raw statistics of a folded norm
     static unsigned long long attr_mask = 0;

@@ -15,8 +15,8 @@
 // The per-tile column vectors (bias; for the consumer of a folded norm the column sums, bias' and the rows' statistics) come in
 // by LDS-DMA one tile ahead into double-buffered LDS behind the ring.
 //
-// Scope: bias / GELU / quick-GELU epilogues (the qkv and fc1 linears), N a multiple of 256, no CLS-skipping loader, no
-// stream-K tail; everything else stays on gemm256.hip (the launcher there decides).  VLLM_GEMM_PERSIST=0 switches it off.
+// Scope: bias / GELU / quick-GELU epilogues (the qkv and fc1 linears), N a multiple of 8, no CLS-skipping loader, no
+// stream-K tail (the launcher prefers this schedule to it); everything else stays on gemm256.hip (the launcher there decides).  VLLM_GEMM_PERSIST=0 switches it off.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -132,13 +132,16 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             }
             if (wave < 2) {   // 256 floats = one 1 KiB instruction: wave 0 the column sums, wave 1 the biases (a missing vector stays zero)
                 const float *vec = wave == 0 ? a.ln_colsum : a.ln_bias;
-                if (vec) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vec + nn + lane * 4),
+                int c4 = nn + lane * 4;
+                c4 = c4 + 4 <= a.N ? c4 : a.N - 4;      // (ragged last column tile: in bounds, the lanes beyond N are not stored)
+                if (vec) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vec + c4),
                                                           (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048 + wave * 1024), 16, 0, 0);
             }
         } else {
             if (wave == 0 && a.bias) {   // 256 bf16 = 512 bytes: the upper 32 lanes re-read the last 16 bytes (harmless, in bounds)
-                const int c8 = lane < 32 ? lane : 31;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.bias + nn + c8 * 8),
+                int c8 = nn + (lane < 32 ? lane : 31) * 8;
+                c8 = c8 + 8 <= a.N ? c8 : a.N - 8;      // (ragged last column tile: in bounds, the lanes beyond N are not stored)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.bias + c8),
                                                  (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048), 16, 0, 0);
             }
         }
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
     }
     // a lane's part of the output address: row wr * 16 MT + fr of a quadrant piece; after the lane-row exchange of the epilogue
     // lane row kq holds the 8 features from column {0, 16, 8, 24}[kq] of the wave's 32
-    const unsigned yvo = ((unsigned)(wr * (16 * MT) + fr) * (unsigned)a.ldy + (unsigned)(wc * 32 + (kq & 1) * 16 + (kq >> 1) * 8)) * 2u;
+    const int ycol = wc * 32 + (kq & 1) * 16 + (kq >> 1) * 8;
+    const unsigned yvo = ((unsigned)(wr * (16 * MT) + fr) * (unsigned)a.ldy + (unsigned)ycol) * 2u;
 
     bf16x8_t wg[2][2], xf[MT][2], wf[2][2];
     f32x4_t acc[4][2][MT];   // [quadrant q = 2 * (A half) + (B half)][n tile][m tile]
@@ -305,7 +309,12 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                     for (int j = 0; j < MT; ++j) rn[qi][j] = reinterpret_cast<const float2_t *>(smem + P_TAB)[qi * HM + wr * (16 * MT) + j * 16 + fr];
             }
             u32x4_t o_prev = {0u, 0u, 0u, 0u};
-            unsigned so_prev = 0u;
+            unsigned so_prev = 0u, yv_prev = 0u;
+            // last column tile of an N that is not a multiple of 256: a lane whose 8 features lie beyond N stores out of the
+            // descriptor's range (dropped)
+            unsigned yv[2];
+#pragma unroll
+            for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int qi = q >> 1, qj = q & 1;
@@ -340,13 +349,14 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                     // the store of a piece goes out one piece LATER (behind the next piece's arithmetic): issued right behind
                     // the lane-row exchange it picked up stale data in the last lanes of every lane row (rows fr >= 12 wrong,
                     // run-to-run different) -- the exchange's result is not interlocked against a vector-memory read
-                    if (q + j > 0 && !(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yvo, (int)so_prev, 0);   // (prof bit 1: ablation, no stores)
+                    if (q + j > 0 && !(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yv_prev, (int)so_prev, 0);   // (prof bit 1: ablation, no stores)
                     o_prev = (u32x4_t){lo.x, hi.x, lo.y, hi.y};
+                    yv_prev = yv[qj];
                     so_prev = ((unsigned)(m0 + qi * HM + j * 16) * (unsigned)a.ldy + (unsigned)(n0 + qj * 128)) * 2u;
                 }
             }
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the same distance for the last piece)
-            if (!(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yvo, (int)so_prev, 0);
+            if (!(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yv_prev, (int)so_prev, 0);
         }
         if (a.prof) {   // (summed per block, written once at its end: an atomic per tile would sit in front of the next tile's refills)
             const unsigned t_c = (unsigned)__builtin_amdgcn_s_memtime();
@@ -381,7 +391,7 @@ bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
     if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
     if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU)) return false;
     if (a.ln_out || a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
-    if ((a.N % P_BN) != 0 || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
+    if ((a.N & 7) != 0 || a.N < P_BN || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!al16(a.X) || !al16(a.W) || !al16(a.Y) || (a.bias && !al16(a.bias))) return false;
     const unsigned long long lim = 1ull << 31;   // byte offsets are 32-bit and must stay clear of the range check's wrap
