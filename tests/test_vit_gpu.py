@@ -281,6 +281,47 @@ def test_gemm256_persistent_schedule(M, N, K, epi, force, pad, bias):
     ulp_close(ys[0][rows, :N], z, 1.0, mag, 2.0 ** -17, f"gemm persistent epi={epi} force={force:#x} M{M} N{N} K{K}")
 
 
+@pytest.mark.parametrize("M,N,K,force,pad,scaled", [
+    (23080, 1024, 1024, 0, 0, False),          # ViT-L proj (CLIP: no LayerScale)
+    (23080, 1024, 4096, 0, 0, False),          # ViT-L fc2
+    (41000, 3200, 3200, 0, 0, True),           # InternViT-6B proj: LayerScale, 12.5 column tiles
+    (16500, 2048, 512, 0x300, 0, True),        # 192-row tiles
+    (9000, 2048, 192, 0x200, 64, True),        # odd number of K tiles, strided X / W / Y / residual
+    (70001, 256, 128, 0x200, 0, False),        # one column tile, the shortest K, ragged last row tile
+])
+def test_gemm256_persistent_residual(M, N, K, force, pad, scaled):
+    """The residual epilogue (proj / fc2) on the persistent schedule: y = res + (x W^T + b) * ls with the residual tile read
+    in the store layout.  Against fp64 to one bf16 ulp, run-to-run identical, nothing outside [M, N]; the one-workgroup-per-tile
+    kernel (residual as the accumulators' initial value: another summation order) within the same bound."""
+    torch.manual_seed(M + N + K)
+    L = _lib.lib()
+    ldx, ldw, ldy = K + pad, K + pad, N + pad
+    x = bf(torch.randn(M, ldx, device=DEV))
+    w = bf(torch.randn(N, ldw, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    ls = bf(0.1 + 0.05 * torch.randn(N, device=DEV)) if scaled else None
+    res = bf(torch.randn(M, ldy, device=DEV))
+    ys = []
+    before = L.vllm_gemm_persistent_launches()
+    for flags in (force, force, force | 0x1000):
+        y = torch.full((M + 300, ldy), 7.0, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, ldx, ldw, ldy, 3 | flags, P(ls) if scaled else None, P(res), ldy, 0, stream()))
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert L.vllm_gemm_persistent_launches() - before == 2, "the persistent schedule was not taken"
+    assert torch.equal(ys[0], ys[1]), "persistent residual epilogue: run-to-run difference"
+    assert (ys[0][M:] == 7.0).all() and (ys[0][:, N:] == 7.0).all(), "wrote outside the output block"
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)]).to(DEV)
+    z = x[rows, :K].double() @ w[:, :K].double().t() + b.double()
+    mag = x[rows, :K].double().abs() @ w[:, :K].double().abs().t() + b.double().abs()
+    lsd = ls.double() if scaled else 1.0
+    z = res[rows, :N].double() + z * lsd
+    mag = res[rows, :N].double().abs() + mag * (ls.double().abs() if scaled else 1.0)
+    ulp_close(ys[0][rows, :N], z, 1.0, mag, 2.0 ** -17, f"gemm persistent residual force={force:#x} M{M} N{N} K{K}")
+    ulp_close(ys[2][rows, :N], z, 1.0, mag, 2.0 ** -16, f"gemm tilewise residual force={force:#x} M{M} N{N} K{K}")
+    assert (ys[0][:M, :N] != ys[2][:M, :N]).float().mean().item() < 0.05
+
+
 @pytest.mark.parametrize("rms", [0, 1])
 @pytest.mark.parametrize("M,C,N,force", [(1154, 1024, 3072, 0x200), (1154, 1024, 4096, 0x300), (700, 960, 1024, 0x200), (2050, 1024, 1024, 0),
                                          (23080, 1024, 3072, 0), (16448, 1024, 4096, 0x300)])

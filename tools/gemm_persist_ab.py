@@ -19,17 +19,19 @@ L = _lib.lib()
 st = _lib.current_stream()
 P = _lib.ptr
 M = 23080
-for name, N, K, epi in (("qkv", 3072, 1024, 0), ("fc1", 4096, 1024, 2), ("ivit_qkv", 9600, 3200, 0), ("ivit_fc1", 12800, 3200, 1)):
+for name, N, K, epi in (("qkv", 3072, 1024, 0), ("fc1", 4096, 1024, 2), ("proj", 1024, 1024, 3), ("fc2", 1024, 4096, 3), ("ivit_qkv", 9600, 3200, 0), ("ivit_fc1", 12800, 3200, 1),
+                         ("ivit_fc2", 3200, 12800, 3)):
     Mx = M if K == 1024 else 8200
     x = torch.randn(Mx, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
     b = torch.randn(N, device="cuda").bfloat16()
     y = torch.empty(Mx, N, device="cuda", dtype=torch.bfloat16)
+    res = torch.randn(Mx, N, device="cuda").bfloat16() if epi == 3 else None
     legs = {"persistent": 0, "tilewise": 0x1000}
     if PHASES:
         buf = (ctypes.c_long * 16)()
         for k, fl in legs.items():
-            f = lambda: _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), Mx, N, K, K, K, N, epi | fl, None, None, 0, 0, st))  # noqa: E731
+            f = lambda: _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), Mx, N, K, K, K, N, epi | fl, None, P(res) if epi == 3 else None, N if epi == 3 else 0, 0, st))  # noqa: E731
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
@@ -47,7 +49,7 @@ for name, N, K, epi in (("qkv", 3072, 1024, 0), ("fc1", 4096, 1024, 2), ("ivit_q
     times = {k: [] for k in legs}
     for rnd in range(4):
         for k, fl in legs.items():
-            f = lambda: _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), Mx, N, K, K, K, N, epi | fl, None, None, 0, 0, st))  # noqa: E731
+            f = lambda: _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), Mx, N, K, K, K, N, epi | fl, None, P(res) if epi == 3 else None, N if epi == 3 else 0, 0, st))  # noqa: E731
             for _ in range(5):
                 f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -44,6 +44,26 @@ constexpr int P_LDS = P_RAW + 2 * 8192;           // 150 KiB
 
 __device__ unsigned long long g_p_prof[8];        // VLLM_GEMM_PROF: ticks of wave 0: main loops, epilogues, tiles, K tile 0 / 1 / 2 / 3 of a tile
 
+// v_permlane16_swap_b32 a, b: the odd lane rows (16 lanes each) of a change places with the even lane rows of b --
+//   a = [a.row0, b.row0, a.row2, b.row2],  b = [a.row1, b.row1, a.row3, b.row3].
+// Inline, with its own wait states: (1) this compiler loses the SECOND result when the two are used separately (it reads both
+// from the first register and reuses the second: seen in the disassembly of a four-line kernel), (2) a vector-memory read or a
+// write of the registers right behind the instruction raced with it (last lanes of each lane row stale, run-to-run different).
+__device__ __forceinline__ void lane_row_swap(unsigned &a, unsigned &b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+}
+
+// One 16-byte output store.  The data registers stay untouched for 16 wait states behind it: with the next instruction but one
+// writing the first of them (the compiler's hazard table has no entry for a 16-byte store with a scalar offset) the first
+// dword came out stale in the last lanes of each lane row, run-to-run different, in the wave group that stores into a busy
+// address path.
+__device__ __forceinline__ void store_piece(u32x4_t &o, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)voff, (int)soff, 0);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o));
+}
+
 #define P_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define P_BARRIER()                       \
     do {                                  \
@@ -54,7 +74,9 @@ __device__ unsigned long long g_p_prof[8];        // VLLM_GEMM_PROF: ticks of wa
 template <int EPI, int MT, bool LNC>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a)
 {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU, "persistent schedule: bias / GELU / quick-GELU epilogues");
+    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU || (EPI == EPI_RESIDUAL && !LNC),
+                  "persistent schedule: bias / GELU / quick-GELU / residual epilogues");
+    constexpr bool RES = EPI == EPI_RESIDUAL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, kq = lane >> 4;
@@ -144,6 +166,12 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.bias + c8),
                                                  (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048), 16, 0, 0);
             }
+            if (RES && wave == 1 && a.scale) {   // LayerScale of the residual epilogue, the same way, 1 KiB further
+                int c8 = nn + (lane < 32 ? lane : 31) * 8;
+                c8 = c8 + 8 <= a.N ? c8 : a.N - 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.scale + c8),
+                                                 (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048 + 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -163,6 +191,25 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
     // lane row kq holds the 8 features from column {0, 16, 8, 24}[kq] of the wave's 32
     const int ycol = wc * 32 + (kq & 1) * 16 + (kq >> 1) * 8;
     const unsigned yvo = ((unsigned)(wr * (16 * MT) + fr) * (unsigned)a.ldy + (unsigned)ycol) * 2u;
+
+    // residual epilogue: the residual tile is read in the SAME lane layout the stores use (16 bytes = 8 features of one row per
+    // lane), with inline buffer loads: a compiler-visible load in front of the stores would make every use wait for vmcnt(0)
+    // (loads and stores retire out of order with each other), i.e. for the store just issued.  Descriptor built by hand for the asm.
+    const u32x4_t rrs = {(unsigned)(reinterpret_cast<uintptr_t>(a.res) & 0xffffffffu), (unsigned)(reinterpret_cast<uintptr_t>(a.res) >> 32) & 0xffffu,
+                         RES ? ((unsigned)(a.M - 1) * (unsigned)a.ldr + (unsigned)a.N) * 2u : 0u, 0x00020000u};
+    const unsigned rvo = ((unsigned)(wr * (16 * MT) + fr) * (unsigned)a.ldr + (unsigned)ycol) * 2u;
+    u32x4_t ra[RES ? MT : 1], rb[RES ? 3 * MT : 1];   // residual pieces of quadrant 0 / of quadrants 1, 2, 3
+    auto res_load_q = [&](u32x4_t *dst, int q, int mm, int nn) {
+        if constexpr (RES) {
+            const int qi = q >> 1, qj = q & 1;
+            const unsigned vo = nn + qj * 128 + ycol + 8 <= a.N ? rvo : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const unsigned so = ((unsigned)(mm + qi * HM + j * 16) * (unsigned)a.ldr + (unsigned)(nn + qj * 128)) * 2u;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst[j]) : "v"(vo), "s"(rrs), "s"(so) : "memory");
+            }
+        }
+    };
 
     bf16x8_t wg[2][2], xf[MT][2], wf[2][2];
     f32x4_t acc[4][2][MT];   // [quadrant q = 2 * (A half) + (B half)][n tile][m tile]
@@ -250,8 +297,20 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             if (a.prof && t < 4) t_k[t] = (unsigned)__builtin_amdgcn_s_memtime();   // (clock: the first K tiles of a tile, one by one)
         };
         k_tile(0, std::true_type{});
+        if constexpr (RES) {
+            // the residual pieces of quadrant 0 are requested in front of the last K tile (more than one quadrant's worth does
+            // not fit beside the fragments: the compiler would spill the in-flight registers).  They are NOT retired by that
+            // K tile's counted wait: a load into registers and the LDS-DMA refills return out of order with each other (seen:
+            // the last piece's first dword stale in the wave group that enters the epilogue without slack) -- the epilogue
+            // waits for them with vmcnt(0).
 #pragma unroll 1
-        for (int t = 1; t < nk; ++t) k_tile(t, std::false_type{});
+            for (int t = 1; t < nk - 1; ++t) k_tile(t, std::false_type{});
+            res_load_q(ra, 0, m0, n0);
+            k_tile(nk - 1, std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int t = 1; t < nk; ++t) k_tile(t, std::false_type{});
+        }
         if (wr == 0) P_BARRIER();   // level again
         par = (par + nk) & 1;
         const unsigned t_b = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
@@ -294,6 +353,63 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             }
             P_WAIT_LGKM0(); P_BARRIER();
         }
+        if constexpr (RES) {
+            // ---- residual epilogue: y = res + (acc + bias) * LayerScale, one rounding.  The lane-row exchange is done on the fp32
+            // values (four exchanges per piece), the residual added in the exchanged layout.  Quadrant 0's residual pieces were
+            // requested a K tile ago (waited for here); those of quadrants 1-3 are requested now (the fragment registers are
+            // free), in front of every store of this tile, and waited for once (vmcnt(0)) behind quadrant 0.
+            if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]) :: "memory");
+            res_load_q(rb, 1, m0, n0); res_load_q(rb + MT, 2, m0, n0); res_load_q(rb + 2 * MT, 3, m0, n0);
+            const char *colb = smem + P_COL + buf * 2048;
+            const bool scaled = a.scale != nullptr;
+            u32x4_t o_prev = {0u, 0u, 0u, 0u};
+            unsigned so_prev = 0u, yv_prev = 0u;
+            unsigned yv[2];
+#pragma unroll
+            for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qi = q >> 1, qj = q & 1;
+                if (q == 1) {
+                    if constexpr (MT == 4)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]),
+                                                            "+v"(rb[8]), "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]) :: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]),
+                                                            "+v"(rb[8]) :: "memory");
+                }
+                float bia[2][4], scl[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int nl = qj * 128 + wc * 32 + i * 16 + kq * 4;
+                    const uint2_t b = *reinterpret_cast<const uint2_t *>(colb + nl * 2);
+                    bia[i][0] = bf16lo_to_f32(b.x); bia[i][1] = bf16hi_to_f32(b.x); bia[i][2] = bf16lo_to_f32(b.y); bia[i][3] = bf16hi_to_f32(b.y);
+                    const uint2_t sc = *reinterpret_cast<const uint2_t *>(colb + 1024 + nl * 2);
+                    scl[i][0] = bf16lo_to_f32(sc.x); scl[i][1] = bf16hi_to_f32(sc.x); scl[i][2] = bf16lo_to_f32(sc.y); scl[i][3] = bf16hi_to_f32(sc.y);
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    float y[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v0 = acc[q][0][j][k] + bia[0][k], v1 = acc[q][1][j][k] + bia[1][k];
+                        if (scaled) { v0 *= scl[0][k]; v1 *= scl[1][k]; }
+                        unsigned s0 = __builtin_bit_cast(unsigned, v0), s1 = __builtin_bit_cast(unsigned, v1);
+                        lane_row_swap(s0, s1);
+                        y[k] = __builtin_bit_cast(float, s0); y[4 + k] = __builtin_bit_cast(float, s1);
+                    }
+                    const u32x4_t rr = q == 0 ? ra[j] : rb[(q - 1) * MT + j];
+                    y[0] += bf16lo_to_f32(rr.x); y[1] += bf16hi_to_f32(rr.x); y[2] += bf16lo_to_f32(rr.y); y[3] += bf16hi_to_f32(rr.y);
+                    y[4] += bf16lo_to_f32(rr.z); y[5] += bf16hi_to_f32(rr.z); y[6] += bf16lo_to_f32(rr.w); y[7] += bf16hi_to_f32(rr.w);
+                    if (q + j > 0 && !(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);
+                    o_prev = (u32x4_t){pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+                    yv_prev = yv[qj];
+                    so_prev = ((unsigned)(m0 + qi * HM + j * 16) * (unsigned)a.ldy + (unsigned)(n0 + qj * 128)) * 2u;
+                }
+            }
+            if (!(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);
+        } else
         // ---- epilogue: straight from the accumulators, nothing waits for the stores ----
         // A lane holds 4 features (8 bytes packed) of row fr in each of the wave's two 16-column n tiles; v_permlane16_swap
         // exchanges the odd lane rows of the first with the even lane rows of the second, after which a lane owns 8 CONSECUTIVE
@@ -344,19 +460,19 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                         else epi_value<EPI>(a, 0, 0, acc[q][i][j], cols[i], v);
                         pk[i][0] = pack_bf16x2(v[0], v[1]); pk[i][1] = pack_bf16x2(v[2], v[3]);
                     }
-                    const u32x2_t lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                    const u32x2_t hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    lane_row_swap(pk[0][0], pk[1][0]);
+                    lane_row_swap(pk[0][1], pk[1][1]);
                     // the store of a piece goes out one piece LATER (behind the next piece's arithmetic): issued right behind
                     // the lane-row exchange it picked up stale data in the last lanes of every lane row (rows fr >= 12 wrong,
-                    // run-to-run different) -- the exchange's result is not interlocked against a vector-memory read
-                    if (q + j > 0 && !(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yv_prev, (int)so_prev, 0);   // (prof bit 1: ablation, no stores)
-                    o_prev = (u32x4_t){lo.x, hi.x, lo.y, hi.y};
+                    // run-to-run different)
+                    if (q + j > 0 && !(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);   // (prof bit 1: ablation, no stores)
+                    o_prev = (u32x4_t){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                     yv_prev = yv[qj];
                     so_prev = ((unsigned)(m0 + qi * HM + j * 16) * (unsigned)a.ldy + (unsigned)(n0 + qj * 128)) * 2u;
                 }
             }
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the same distance for the last piece)
-            if (!(a.prof & 2)) __builtin_amdgcn_raw_buffer_store_b128(o_prev, yrs, (int)yv_prev, (int)so_prev, 0);
+            if (!(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);
         }
         if (a.prof) {   // (summed per block, written once at its end: an atomic per tile would sit in front of the next tile's refills)
             const unsigned t_c = (unsigned)__builtin_amdgcn_s_memtime();
@@ -389,11 +505,13 @@ bool persist_disabled()
 bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
 {
     if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
-    if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU)) return false;
+    if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU || epi == EPI_RESIDUAL)) return false;
     if (a.ln_out || a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
     if ((a.N & 7) != 0 || a.N < P_BN || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!al16(a.X) || !al16(a.W) || !al16(a.Y) || (a.bias && !al16(a.bias))) return false;
+    if (epi == EPI_RESIDUAL && (a.ln_in || !a.res || !al16(a.res) || (a.ldr & 3) != 0 || (a.scale && !al16(a.scale)) ||
+                                ((unsigned long long)a.M + 256) * (unsigned long long)a.ldr * 2 >= (1ull << 31))) return false;
     const unsigned long long lim = 1ull << 31;   // byte offsets are 32-bit and must stay clear of the range check's wrap
     if (((unsigned long long)a.M + 256) * (unsigned long long)a.ldx * 2 >= lim || ((unsigned long long)a.N + 256) * (unsigned long long)a.ldw * 2 >= lim ||
         ((unsigned long long)a.M + 256) * (unsigned long long)a.ldy * 2 >= lim) return false;
@@ -414,14 +532,17 @@ int gemm256p_launch(int epi, int MT, const GemmArgs &a, int cus, hipStream_t st)
 #define SETATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 4, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
                       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS)
         SETATTR(EPI_BIAS, false); SETATTR(EPI_GELU, false); SETATTR(EPI_QUICK_GELU, false);
-        SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true);
+        SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true); SETATTR(EPI_RESIDUAL, false);
 #undef SETATTR
     }
 #define LAUNCH(E) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true>), grid, block, P_LDS, st, a); \
                                        else VLLM_LAUNCH((gemm256p_kernel<E, 3, true>), grid, block, P_LDS, st, a); } \
                        else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false>), grid, block, P_LDS, st, a); \
                               else VLLM_LAUNCH((gemm256p_kernel<E, 3, false>), grid, block, P_LDS, st, a); } } while (0)
-    if (epi == EPI_BIAS) LAUNCH(EPI_BIAS); else if (epi == EPI_GELU) LAUNCH(EPI_GELU); else LAUNCH(EPI_QUICK_GELU);
+    if (epi == EPI_RESIDUAL) {
+        if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false>), grid, block, P_LDS, st, a);
+        else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false>), grid, block, P_LDS, st, a);
+    } else if (epi == EPI_BIAS) LAUNCH(EPI_BIAS); else if (epi == EPI_GELU) LAUNCH(EPI_GELU); else LAUNCH(EPI_QUICK_GELU);
 #undef LAUNCH
     VLLM_CHECK_LAUNCH("gemm256p_kernel");
     return VLLM_OK;
