@@ -344,6 +344,21 @@ def test_gemm_folded_norm(M, C, N, force, rms):
     stats = torch.full((M, nt, 2), float("nan"), dtype=torch.float32, device=DEV)
     _lib.check(L.vllm_gemm_bf16_ln(P(x0), P(w0), P(b0), P(h), M, C, K0, K0, K0, C, 3 | (force if force else 0x200), None, P(res), C,
                                    P(stats), None, 0, rms, eps, None, None, stream()))
+    # the same producer once more (run-to-run identical) and as one workgroup per tile (where the persistent schedule took it:
+    # another combination order of the partial statistics, the same stored values up to the residual's summation order)
+    h2 = torch.empty_like(h)
+    stats2 = torch.full_like(stats, float("nan"))
+    _lib.check(L.vllm_gemm_bf16_ln(P(x0), P(w0), P(b0), P(h2), M, C, K0, K0, K0, C, 3 | (force if force else 0x200), None, P(res), C,
+                                   P(stats2), None, 0, rms, eps, None, None, stream()))
+    assert torch.equal(h, h2) and torch.equal(stats, stats2), "folded norm, producer: run-to-run difference"
+    h3 = torch.empty_like(h)
+    stats3 = torch.full_like(stats, float("nan"))
+    _lib.check(L.vllm_gemm_bf16_ln(P(x0), P(w0), P(b0), P(h3), M, C, K0, K0, K0, C, 3 | (force if force else 0x200) | 0x1000, None, P(res), C,
+                                   P(stats3), None, 0, rms, eps, None, None, stream()))
+    same = (h == h3).all(dim=1)                                   # rows the two kernels rounded identically: their statistics agree
+    torch.testing.assert_close(stats[same][..., 0], stats3[same][..., 0], rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(stats[same][..., 1], stats3[same][..., 1], rtol=2e-5, atol=1e-5)
+    assert same.float().mean().item() > 0.5
     hd = h.double()
     for tcol in range(nt):
         blk = hd[:, tcol * 256:(tcol + 1) * 256]

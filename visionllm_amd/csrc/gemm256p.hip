@@ -54,6 +54,26 @@ __device__ __forceinline__ void lane_row_swap(unsigned &a, unsigned &b)
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
 }
 
+// v_permlane32_swap_b32 a, b: the upper 32 lanes of a change places with the lower 32 lanes of b (same guards as above).
+__device__ __forceinline__ void lane_half_swap(unsigned &a, unsigned &b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+}
+// {mean, M2} of n values each, held by lane pairs 16 (STEP 16) or 32 (STEP 32) lanes apart -> {mean, M2} of the 2n values, in
+// both lanes, combined in a fixed order (lower lanes first): Chan's update for equal counts.  rms: plain sums of squares.
+template <int STEP>
+__device__ __forceinline__ void pair_combine(float &mean, float &m2, float half_n, bool rms)
+{
+    unsigned ma = __builtin_bit_cast(unsigned, mean), mb = ma, qa = __builtin_bit_cast(unsigned, m2), qb = qa;
+    if (STEP == 16) { lane_row_swap(ma, mb); lane_row_swap(qa, qb); } else { lane_half_swap(ma, mb); lane_half_swap(qa, qb); }
+    const float fa = __builtin_bit_cast(float, ma), fb = __builtin_bit_cast(float, mb);
+    const float ga = __builtin_bit_cast(float, qa), gb = __builtin_bit_cast(float, qb);
+    if (rms) { mean = fa + fb; m2 = 0.f; return; }
+    const float d = fb - fa;
+    mean = fmaf(0.5f, d, fa);
+    m2 = fmaf(d * d, half_n, ga + gb);
+}
+
 // One 16-byte output store.  The data registers stay untouched for 16 wait states behind it: with the next instruction but one
 // writing the first of them (the compiler's hazard table has no entry for a 16-byte store with a scalar offset) the first
 // dword came out stale in the last lanes of each lane row, run-to-run different, in the wave group that stores into a busy
@@ -71,12 +91,13 @@ __device__ __forceinline__ void store_piece(u32x4_t &o, __amdgpu_buffer_rsrc_t r
         __builtin_amdgcn_sched_barrier(0);\
     } while (0)
 
-template <int EPI, int MT, bool LNC>
+template <int EPI, int MT, bool LNC, bool STATS = false>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a)
 {
     static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU || (EPI == EPI_RESIDUAL && !LNC),
                   "persistent schedule: bias / GELU / quick-GELU / residual epilogues");
     constexpr bool RES = EPI == EPI_RESIDUAL;
+    static_assert(!STATS || RES, "row statistics for a folded norm: the residual epilogue produces them");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, kq = lane >> 4;
@@ -366,6 +387,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             u32x4_t o_prev = {0u, 0u, 0u, 0u};
             unsigned so_prev = 0u, yv_prev = 0u;
             unsigned yv[2];
+            float st_m[STATS ? MT : 1], st_q[STATS ? MT : 1];   // a lane's {mean, M2} of the qj = 0 pieces, until their qj = 1 partners
 #pragma unroll
             for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
 #pragma unroll
@@ -404,11 +426,62 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                     y[4] += bf16lo_to_f32(rr.z); y[5] += bf16hi_to_f32(rr.z); y[6] += bf16lo_to_f32(rr.w); y[7] += bf16hi_to_f32(rr.w);
                     if (q + j > 0 && !(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);
                     o_prev = (u32x4_t){pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+                    if constexpr (STATS) {
+                        // folded norm, producer side: {mean, M2} ({sum of squares, -} for RMSNorm) of the bf16 values just packed,
+                        // per output row and 256-column tile -- 8 values here, the row's other 8 of this lane when qj = 1, then
+                        // the 4 lane rows, then (through LDS) the 4 waves that share the row
+                        const unsigned u[4] = {o_prev.x, o_prev.y, o_prev.z, o_prev.w};
+                        float x_[8];
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) { x_[2 * k2] = bf16lo_to_f32(u[k2]); x_[2 * k2 + 1] = bf16hi_to_f32(u[k2]); }
+                        float pm, pq = 0.f;
+                        if (a.ln_rms) {
+                            pm = 0.f;
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) pm = fmaf(x_[k2], x_[k2], pm);
+                        } else {
+                            pm = ((x_[0] + x_[1]) + (x_[2] + x_[3])) + ((x_[4] + x_[5]) + (x_[6] + x_[7]));
+                            pm *= 0.125f;
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) { const float d = x_[k2] - pm; pq = fmaf(d, d, pq); }
+                        }
+                        if (qj == 0) { st_m[j] = pm; st_q[j] = pq; }
+                        else {
+                            float mean = st_m[j], m2 = st_q[j];
+                            if (a.ln_rms) mean += pm;
+                            else { const float d = pm - mean; mean = fmaf(0.5f, d, mean); m2 = fmaf(d * d, 4.f, m2 + pq); }
+                            pair_combine<16>(mean, m2, 8.f, a.ln_rms != 0);
+                            pair_combine<32>(mean, m2, 16.f, a.ln_rms != 0);
+                            if (kq == 0) reinterpret_cast<float2_t *>(smem + P_RAW)[(qi * HM + wr * (16 * MT) + j * 16 + fr) * 4 + wc] = (float2_t){mean, m2};
+                        }
+                    }
                     yv_prev = yv[qj];
                     so_prev = ((unsigned)(m0 + qi * HM + j * 16) * (unsigned)a.ldy + (unsigned)(n0 + qj * 128)) * 2u;
                 }
             }
             if (!(a.prof & 2)) store_piece(o_prev, yrs, yv_prev, so_prev);
+            if constexpr (STATS) {
+                P_WAIT_LGKM0(); P_BARRIER();
+                if (tid < BM) {   // the four waves' partials (64 values each) of row tid, in a fixed order
+                    float2_t pp[4];
+                    {
+                        const unsigned addr = (unsigned)(size_t)(smem + P_RAW + tid * 32);   // (inline: see the folded-norm consumer)
+                        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(pp[0]), "=&v"(pp[1]), "=&v"(pp[2]), "=&v"(pp[3]) : "v"(addr) : "memory");
+                    }
+                    float2_t r_;
+                    if (a.ln_rms) r_ = (float2_t){(pp[0].x + pp[1].x) + (pp[2].x + pp[3].x), 0.f};
+                    else {
+                        const float d0 = pp[1].x - pp[0].x, d1 = pp[3].x - pp[2].x;
+                        const float m0_ = fmaf(0.5f, d0, pp[0].x), m1_ = fmaf(0.5f, d1, pp[2].x);
+                        const float q0_ = fmaf(d0 * d0, 32.f, pp[0].y + pp[1].y), q1_ = fmaf(d1 * d1, 32.f, pp[2].y + pp[3].y);
+                        const float d = m1_ - m0_;
+                        r_ = (float2_t){fmaf(0.5f, d, m0_), fmaf(d * d, 64.f, q0_ + q1_)};
+                    }
+                    const int m = m0 + tid;
+                    if (m < a.M) *reinterpret_cast<float2_t *>(a.ln_out + ((size_t)m * a.nt + (n0 >> 8)) * 2) = r_;
+                }
+            }
         } else
         // ---- epilogue: straight from the accumulators, nothing waits for the stores ----
         // A lane holds 4 features (8 bytes packed) of row fr in each of the wave's two 16-column n tiles; v_permlane16_swap
@@ -506,7 +579,8 @@ bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
 {
     if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
     if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU || epi == EPI_RESIDUAL)) return false;
-    if (a.ln_out || a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
+    if (a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
+    if (a.ln_out && (epi != EPI_RESIDUAL || (a.N % P_BN) != 0 || (reinterpret_cast<uintptr_t>(a.ln_out) & 7u) != 0)) return false;
     if ((a.N & 7) != 0 || a.N < P_BN || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!al16(a.X) || !al16(a.W) || !al16(a.Y) || (a.bias && !al16(a.bias))) return false;
@@ -533,13 +607,18 @@ int gemm256p_launch(int epi, int MT, const GemmArgs &a, int cus, hipStream_t st)
                       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS)
         SETATTR(EPI_BIAS, false); SETATTR(EPI_GELU, false); SETATTR(EPI_QUICK_GELU, false);
         SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true); SETATTR(EPI_RESIDUAL, false);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
 #undef SETATTR
     }
 #define LAUNCH(E) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true>), grid, block, P_LDS, st, a); \
                                        else VLLM_LAUNCH((gemm256p_kernel<E, 3, true>), grid, block, P_LDS, st, a); } \
                        else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false>), grid, block, P_LDS, st, a); \
                               else VLLM_LAUNCH((gemm256p_kernel<E, 3, false>), grid, block, P_LDS, st, a); } } while (0)
-    if (epi == EPI_RESIDUAL) {
+    if (epi == EPI_RESIDUAL && a.ln_out) {
+        if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), grid, block, P_LDS, st, a);
+        else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), grid, block, P_LDS, st, a);
+    } else if (epi == EPI_RESIDUAL) {
         if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false>), grid, block, P_LDS, st, a);
         else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false>), grid, block, P_LDS, st, a);
     } else if (epi == EPI_BIAS) LAUNCH(EPI_BIAS); else if (epi == EPI_GELU) LAUNCH(EPI_GELU); else LAUNCH(EPI_QUICK_GELU);
