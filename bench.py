@@ -244,10 +244,13 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         ls = torch.full((n,), 0.1, device=dev).to(torch.bfloat16) if (epi == 3 and has_ls) else None
         f = lambda: _lib.check(L.vllm_gemm_bf16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, n, k, k, k, n, epi,  # noqa: E731
                                                  _lib.ptr(ls), _lib.ptr(res), n if epi == 3 else 0, 0, st))
+        pl0 = L.vllm_gemm_persistent_launches()
         f(); torch.cuda.synchronize()
+        kname = ("gemm256p_kernel [persistent 8-phase schedule]" if L.vllm_gemm_persistent_launches() > pl0 else
+                 "gemm256_bf16_kernel [8-phase schedule, one workgroup per tile]")
         sec = event_time(f, iters)
         fl = 2.0 * m * n * k
-        out[nm] = entry(ptag, f"gemm256_bf16_kernel ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", "mfma", fl, sec, n_launch,
+        out[nm] = entry(ptag, f"{kname} ({names.get(nm, 'projector linear')}: M{m} N{n} K{k})", "mfma", fl, sec, n_launch,
                         MFMA_BF16_PEAK_TF, "TFLOP/s", 1e12, algorithmic_flops=fl)
         del x, w, b, y, res, ls
     # norms (LayerNorm / RMSNorm, incl. InternViT's q / k norms): HBM bound, one read + one write of [M, C] bf16
