@@ -320,10 +320,9 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
         k_tile(0, std::true_type{});
         if constexpr (RES) {
             // the residual pieces of quadrant 0 are requested in front of the last K tile (more than one quadrant's worth does
-            // not fit beside the fragments: the compiler would spill the in-flight registers).  They are NOT retired by that
-            // K tile's counted wait: a load into registers and the LDS-DMA refills return out of order with each other (seen:
-            // the last piece's first dword stale in the wave group that enters the epilogue without slack) -- the epilogue
-            // waits for them with vmcnt(0).
+            // not fit beside the fragments: the compiler would spill the in-flight registers).  That K tile's counted wait is
+            // exact for the refills only (nothing is assumed about the order in which register loads and LDS-DMA retire relative
+            // to each other): the epilogue waits for the pieces with vmcnt(0).
 #pragma unroll 1
             for (int t = 1; t < nk - 1; ++t) k_tile(t, std::false_type{});
             res_load_q(ra, 0, m0, n0);
