@@ -122,3 +122,78 @@ def test_level_geometry_facts_on_the_host():
         assert A.known_geometry(t, lq - 1) == A.GEO_GENERAL                   # the pyramid-item kernel serves the encoder's queries only
         t.mul_(1)
         assert A.known_geometry(t, lq) == A.GEO_UNKNOWN
+
+
+def test_folded_norm_operands_reproduce_norm_then_linear():
+    """Host logic of the folded norms (vit_common.fold_norm_into_linear): with exact row statistics,
+    r (x W'^T) - r mean colsum + bias' equals linear(LayerNorm(x)) for the bf16 weights in use (fp64 here), and the RMSNorm form
+    has neither column sums nor a shifted bias.  The GPU tests check the kernels against this expression."""
+    import torch
+    from visionllm_amd.vit_common import fold_norm_into_linear, norm_folding_applies
+    torch.manual_seed(0)
+    C, N, M, eps = 96, 40, 17, 1e-5
+    x = (torch.randn(M, C) * 2 + 0.7).to(torch.bfloat16).double()
+    w = (torch.randn(N, C) / C ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N).to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(C)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(C)).to(torch.bfloat16)
+    w_ln, colsum, bias_ln = fold_norm_into_linear(w, b, gamma, beta, layernorm=True)
+    assert w_ln.dtype == torch.bfloat16 and colsum.dtype == torch.float32 and bias_ln.dtype == torch.float32
+    mu = x.mean(1, keepdim=True)
+    r = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
+    folded = r * (x @ w_ln.double().t()) - r * mu * colsum.double()[None, :] + bias_ln.double()[None, :]
+    # the same weights the folded GEMM multiplies with: gamma W rounded to bf16 (the reference rounds gamma * xhat instead)
+    direct = ((x - mu) * r) @ w_ln.double().t() + (beta.double() @ w.double().t() + b.double())[None, :]
+    assert (folded - direct).abs().max().item() < 1e-5
+    w_r, colsum_r, bias_r = fold_norm_into_linear(w, b, gamma, None, layernorm=False)
+    assert colsum_r is None and torch.equal(bias_r, b.float()) and torch.equal(w_r, w_ln)
+    r2 = torch.rsqrt((x * x).mean(1, keepdim=True) + eps)
+    assert ((r2 * (x @ w_r.double().t()) + bias_r.double()) - ((x * r2) @ w_r.double().t() + b.double())).abs().max().item() < 1e-9
+    assert norm_folding_applies(1024, 4096) and not norm_folding_applies(3200, 12800)
+
+
+def test_tile_statistics_combine_to_the_row_statistics():
+    """Chan's update as the GEMM epilogues use it: per-tile {mean, M2} of 256 (last tile: fewer) values combine, in a fixed order and
+    with the launcher's constants (n_b / n, n_a n_b / n), to the row's mean and centred second moment; the equal-count form
+    (pairs of 8, 16, 32, 64, 128 values) is the producer's in-register reduction."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    for cols in (1024, 960, 800):
+        x = rng.standard_normal((5, cols)) * 3 + 40.0                      # a mean far from zero: the one-pass form would cancel
+        cnt = mean = m2 = 0.0
+        mean = np.zeros(5); m2 = np.zeros(5); cnt = 0.0
+        for s in range(4):
+            blk = x[:, s * 256:min(cols, (s + 1) * 256)]
+            nb = blk.shape[1]
+            bm = blk.mean(1); bq = ((blk - bm[:, None]) ** 2).sum(1)
+            tot = cnt + nb
+            d = bm - mean
+            mean = mean + d * (nb / tot)
+            m2 = m2 + bq + d * d * (cnt * nb / tot)
+            cnt = tot
+        np.testing.assert_allclose(mean, x.mean(1), rtol=1e-13)
+        np.testing.assert_allclose(m2, ((x - x.mean(1, keepdims=True)) ** 2).sum(1), rtol=1e-12)
+    x = rng.standard_normal((3, 256)) + 7.0
+    parts = [(x[:, i:i + 8].mean(1), ((x[:, i:i + 8] - x[:, i:i + 8].mean(1, keepdims=True)) ** 2).sum(1)) for i in range(0, 256, 8)]
+    n = 8
+    while len(parts) > 1:
+        nxt = []
+        for (ma, qa), (mb, qb) in zip(parts[0::2], parts[1::2]):
+            d = mb - ma
+            nxt.append((ma + 0.5 * d, qa + qb + d * d * (n / 2)))
+        parts, n = nxt, 2 * n
+    np.testing.assert_allclose(parts[0][0], x.mean(1), rtol=1e-13)
+    np.testing.assert_allclose(parts[0][1], ((x - x.mean(1, keepdims=True)) ** 2).sum(1), rtol=1e-12)
+
+
+def test_vit_layer_descriptor_matches_the_header():
+    """The ctypes mirror of VllmVitLayer carries the six folded-norm operands at the END of the struct (a round-2 caller's layout is
+    a prefix of it), in the header's order."""
+    names = [f[0] for f in _lib.VllmVitLayer._fields_]
+    assert names[-6:] == ["qkv_w_ln", "qkv_colsum", "qkv_bias_ln", "fc1_w_ln", "fc1_colsum", "fc1_bias_ln"]
+    assert names[:4] == ["norm1_w", "norm1_b", "qkv_w", "qkv_b"]
+    assert ctypes.sizeof(_lib.VllmVitLayer) == len(names) * ctypes.sizeof(ctypes.c_void_p)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vllm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct VllmVitLayer {"):hdr.index("} VllmVitLayer;")]
+    order = [body.index(n) for n in names]
+    assert order == sorted(order), "field order differs from include/vllm_hip.h"
