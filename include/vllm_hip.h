@@ -333,7 +333,7 @@ typedef struct VllmVitLayer {
     const uint16_t *fc2_w, *fc2_b;       /* [C, I], [C] */
     const uint16_t *ls2;
     /* Optional (all NULL = launch the norms): the norms folded into the GEMMs around them (vllm_gemm_bf16_ln; taken for
-     * hidden >= 1024 and >= 1024 tokens).  *_w_ln = the weight with the norm's gamma multiplied in, bf16, same shape;
+     * hidden == 1024 and >= 1024 tokens).  *_w_ln = the weight with the norm's gamma multiplied in, bf16, same shape;
      * *_colsum[n] = sum_k w_ln[n, k], fp32 (LayerNorm; NULL for RMSNorm); *_bias_ln[n] = b_n + sum_k beta_k w[n, k], fp32
      * (NULL = 0).  Prepared once per weight set by the caller (the Python mirrors do it when they pack the parameters). */
     const uint16_t *qkv_w_ln;

@@ -6,17 +6,22 @@
 // (output tile through LDS + waiting for the stores, 4.9 - 8.5 us) and the gap until the next workgroup starts (1.3 us).  Here
 //   * the K-tile refills of the last two iterations of a tile fetch the first two K tiles of the block's NEXT tile (same ring,
 //     same counted vmcnt(6) once per K tile): when the last MFMA of a tile retires, the next tile's first K tile is in LDS;
-//   * the epilogue stores straight from the accumulators (buffer stores, 8 bytes per lane, rows beyond M dropped by the
-//     descriptor's range check) and does not wait for them: they drain under the next tile's main loop.  vmcnt counts them
-//     together with the refills; loads return in order among themselves, so "at most 6 outstanding" still means "every refill
-//     but the newest six has landed" -- the wait can only be longer than needed, never shorter;
+//   * the epilogue stores straight from the accumulators (after a lane-row exchange 16 bytes = 8 consecutive features per lane;
+//     rows beyond M and the columns of a ragged last tile are dropped by the descriptor's range check) and does not wait for
+//     the stores: they drain under the next tile's main loop.  vmcnt counts them together with the refills; loads return in
+//     order among themselves, so "at most 6 outstanding" still means "every refill but the newest six has landed" -- the wait
+//     can only be longer than needed, never shorter;
 //   * operands are addressed through buffer descriptors: a lane's part of a refill address is one 32-bit offset per DMA slot
-//     (4 registers in all), the tile / K-tile part is scalar -- nothing per-lane changes from tile to tile.
-// The per-tile column vectors (bias; for the consumer of a folded norm the column sums, bias' and the rows' statistics) come in
-// by LDS-DMA one tile ahead into double-buffered LDS behind the ring.
+//     (4 registers in all), the tile / K-tile part is scalar -- nothing per-lane changes from tile to tile;
+//   * K tile 0 of a tile takes the MFMA's constant-zero accumulator; the two staggered wave groups are level around the epilogue.
+// The per-tile column vectors (bias, LayerScale; for the consumer of a folded norm the column sums, bias' and the rows'
+// statistics) come in by LDS-DMA one tile ahead into double-buffered LDS behind the ring.  The residual epilogue reads the
+// residual tile in the store layout with inline buffer loads and can produce a folded norm's row statistics (STATS).
 //
-// Scope: bias / GELU / quick-GELU epilogues (the qkv and fc1 linears), N a multiple of 8, no CLS-skipping loader, no
-// stream-K tail (the launcher prefers this schedule to it); everything else stays on gemm256.hip (the launcher there decides).  VLLM_GEMM_PERSIST=0 switches it off.
+// Scope: bias / GELU / quick-GELU / residual epilogues (qkv, fc1, proj, fc2 and the projector linears), N a multiple of 8, at
+// least as many tiles as CUs, no CLS-skipping loader; the launcher in gemm256.hip asks for this schedule before it considers a
+// stream-K tail.  Everything else stays on gemm256.hip.  VLLM_GEMM_PERSIST=0 / VLLM_GEMM_FORCE_TILEWISE switch it off.
+// Measured and the four properties of the part / toolchain that the guards in this file are for: DESIGN.md section 3.2.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -573,7 +578,8 @@ bool persist_disabled()
 
 }  // namespace
 
-// Whether the persistent schedule takes this GEMM (the 8-phase launcher asks after it has chosen MT and found no stream-K tail).
+// Whether the persistent schedule takes this GEMM (the 8-phase launcher asks BEFORE it considers a stream-K tail, with the tile
+// height that needs fewer whole rounds).
 bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
 {
     if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
