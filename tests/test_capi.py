@@ -197,3 +197,32 @@ def test_vit_layer_descriptor_matches_the_header():
     body = hdr[hdr.index("typedef struct VllmVitLayer {"):hdr.index("} VllmVitLayer;")]
     order = [body.index(n) for n in names]
     assert order == sorted(order), "field order differs from include/vllm_hip.h"
+
+
+def test_persistent_gemm_keeps_in_flight_registers_out_of_scratch(tmp_path):
+    """gemm256p.hip loads the residual tile with inline buffer loads the compiler does not know are loads: if register pressure
+    ever made it spill one of those destination registers it would store the register BEFORE the data has arrived (no wait is
+    inserted for an instruction it cannot see).  The residual instantiations must therefore compile without vector spills --
+    checked here on the code object's metadata (cross-compiles without a GPU)."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "visionllm_amd", "csrc", "gemm256p.hip")
+    out = tmp_path / "gemm256p.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"), "-S",
+                    "--cuda-device-only", src, "-o", str(out)], check=True, cwd=os.path.dirname(src), capture_output=True, timeout=600)
+    text = out.read_text()
+    names = re.findall(r"\.name:\s+(\S*gemm256p_kernel\S*)", text)
+    spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+    assert names and len(names) == len(spills)
+    residual = [(n, int(s)) for n, s in zip(names, spills) if "gemm256p_kernelILi3E" in n]          # EPI_RESIDUAL = 3
+    assert len(residual) == 4, residual                                                             # MT 3 / 4, with / without statistics
+    plain = [(n, s) for n, s in residual if n.endswith("Lb0ELb0EEEvNS_8GemmArgsE")]
+    assert all(s == 0 for _, s in plain), plain
+    # the statistics variant at MT = 4 spills ONE scalar set-up value at the kernel's top (reloaded at its very end): nothing in flight
+    assert all(s <= 1 for _, s in residual), residual
+    others = [(n, int(s)) for n, s in zip(names, spills) if "gemm256p_kernelILi3E" not in n]
+    assert all(s == 0 for _, s in others), others
