@@ -226,3 +226,43 @@ def test_persistent_gemm_keeps_in_flight_registers_out_of_scratch(tmp_path):
     assert all(s <= 1 for _, s in residual), residual
     others = [(n, int(s)) for n, s in zip(names, spills) if "gemm256p_kernelILi3E" not in n]
     assert all(s == 0 for _, s in others), others
+
+
+def test_attention_lane_swaps_read_both_results(tmp_path):
+    """v_permlane32_swap writes BOTH its registers; this toolchain has been seen to fold the builtin's two results into one
+    (profiles/r03_permlane_swap_codegen.txt: r[0] + r[1] compiled to v + v in a small kernel).  The attention kernels combine the
+    two key halves of a row with it (attn_common.hpp: halves_max / halves_sum): every swap in their code objects must be followed
+    by a read of its second register before that register is overwritten."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("attn.hip", "attn2.hip"):
+        src = os.path.join(root, "visionllm_amd", "csrc", name)
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"), "-S",
+                        "--cuda-device-only", src, "-o", str(out)], check=True, cwd=os.path.dirname(src), capture_output=True, timeout=900)
+        lines = [ln for ln in out.read_text().splitlines() if ln.strip() and not ln.strip().startswith(";")]
+        swaps = 0
+        for i, ln in enumerate(lines):
+            m = re.search(r"v_permlane32_swap_b32\S*\s+(v\d+), (v\d+)", ln)
+            if not m:
+                continue
+            swaps += 1
+            second = m.group(2)
+            verdict = None
+            for nxt in lines[i + 1:i + 40]:
+                ops = nxt.split(None, 1)
+                if len(ops) < 2 or not ops[0].startswith(("v_", "ds_", "global_", "buffer_", "scratch_")):
+                    continue
+                dst, _, srcs = ops[1].partition(",")
+                if re.search(r"\b" + second + r"\b", srcs):
+                    verdict = "read"
+                    break
+                if re.fullmatch(second, dst.strip()):
+                    verdict = "overwritten"
+                    break
+            assert verdict == "read", f"{name}: second result of the swap at instruction {i} ({ln.strip()}) is {verdict}"
+        assert swaps > 0, name

@@ -18,6 +18,10 @@ template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 64 
 
 // Combine the two key halves of a query (lanes l and l^32) with ONE v_permlane32_swap instead of a ds_bpermute round
 // trip: swapping x with itself leaves {x_lo, x_lo} in one register and {x_hi, x_hi} in the other.
+// (Toolchain note, round 3: in SMALL kernels this compiler folds the builtin's two results into one register -- r[0] + r[1]
+//  becomes v + v, fmaxf(r[0], r[1]) becomes v: profiles/r03_permlane_swap_codegen.txt.  In the attention kernels both results
+//  are read (tests/test_capi.py::test_attention_lane_swaps_read_both_results scans the disassembly after every build of the
+//  test suite); gemm256p.hip, where the folding did happen, does its exchanges in inline assembly.)
 __device__ __forceinline__ float halves_max(float x)
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
