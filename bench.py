@@ -123,6 +123,88 @@ def event_time(fn, iters, stream=None, rounds=3):
     return float(np.median(ts))
 
 
+class ClockSampler:
+    """Shader clock + package power of the GPU this rank runs on, sampled WHILE the timed steps run (the same
+    binary reads +-10 % on different boxes of the pool; without the clock next to `ms_per_step` a box effect cannot be told from a
+    code effect).  Source: the amdgpu hwmon files (freq1_input = sclk in Hz, power1_average / power1_input in uW) read by a
+    background thread every 20 ms -- a file read, nothing is spawned inside the timed region.  Where they are missing,
+    `rocm-smi --showclocks --showpower` is sampled over a SECOND, untimed run of the same steps (a subprocess per sample)."""
+
+    def __init__(self, dev):
+        import glob
+        self.rows, self._stop, self._th, self.src = [], False, None, None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:
+            pass
+        cands = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = os.path.join(h, "freq1_input")
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            if os.path.exists(f):
+                cands.append((os.path.realpath(os.path.join(h, "..", "..")), f, pw))
+        hit = [c for c in cands if want and want in c[0]]
+        self.files = (hit or cands)[:8 if not hit else 1]
+
+    def _read(self):
+        best = None
+        for _, f, pw in self.files:
+            try:
+                mhz = int(open(f).read()) / 1e6
+                w = int(open(pw).read()) / 1e6 if pw else float("nan")
+            except Exception:
+                continue
+            if best is None or (w if w == w else 0.0) > (best[1] if best[1] == best[1] else 0.0):   # several candidates: the busy one
+                best = (mhz, w)
+        return best
+
+    def _loop_sysfs(self):
+        while not self._stop:
+            r = self._read()
+            if r:
+                self.rows.append(r)
+            time.sleep(0.02)
+
+    def _loop_smi(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                sclk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", o)
+                pw = re.search(r"Power \(W\):\s*([\d.]+)", o)
+                if sclk:
+                    self.rows.append((float(sclk.group(1)), float(pw.group(1)) if pw else float("nan")))
+            except Exception:
+                return
+            time.sleep(0.05)
+
+    def has_sysfs(self):
+        return bool(self.files) and self._read() is not None
+
+    def start(self, sysfs=True):
+        import threading
+        self.rows, self._stop = [], False
+        self.src = "amdgpu hwmon (freq1_input / power1_average), 20 ms period" if sysfs else "rocm-smi --showclocks --showpower"
+        self._th = threading.Thread(target=self._loop_sysfs if sysfs else self._loop_smi, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=10)
+        rows = self.rows[1:] if len(self.rows) > 2 else self.rows     # (the first sample predates the load)
+        if not rows:
+            return None
+        mhz = [r[0] for r in rows]
+        pw = [r[1] for r in rows if r[1] == r[1]]
+        return {"sclk_mhz_median": float(np.median(mhz)), "sclk_mhz_min": float(min(mhz)), "sclk_mhz_max": float(max(mhz)),
+                "power_w_median": float(np.median(pw)) if pw else None, "power_w_max": float(max(pw)) if pw else None,
+                "samples": len(rows), "source": self.src}
+
+
 NONPYR_SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]   # ceil-divided levels of an 800 x 1333 detection input (ADVICE r2)
 
 
@@ -391,8 +473,20 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
     """One workload end to end: build, warm up, time EXACTLY args.steps steps (barrier + synchronize on both sides, max over
     ranks), phases, in-step kernel times, rooflines.  Returns the record (rank 0) or None."""
     from visionllm_amd.dist import all_gather_visual_tokens
+    from visionllm_amd.dist import shard_images
     ivit = workload == "internvit6b"
     n_tiles = IMAGES_PER_RANK * TILES_PER_IMAGE
+    counts = [n_tiles] * world
+    images_total = world * IMAGES_PER_RANK
+    if args.ragged_tiles:
+        # any-res batches are ragged: 1-7 tiles per image (mm_utils.py:39-77).  The GLOBAL batch of world x 8 images gets a fixed
+        # 1..7 pattern, whole images are dealt to the ranks by tile count (dist.shard_images: every image's tiles stay on one
+        # rank, modeling_visionllmv2.py:563), and every rank passes the tile counts of all ranks to the all-gather (no count
+        # exchange, no host sync).  Not the headline workload: the line says so in config.workload.
+        tiles_per_image = [1 + (i * i + 2 * i + 1) % 7 for i in range(images_total)]
+        shards = shard_images(tiles_per_image, world)
+        counts = [sum(tiles_per_image[i] for i in sh) for sh in shards]
+        n_tiles = counts[rank]
     cfg = IVIT if ivit else VIT
     T = (cfg["image_size"] // cfg["patch_size"]) ** 2
     T_out = T // 4 if ivit else T
@@ -451,6 +545,19 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
 
     pending = [None]
     lag = [1]
+    step_no = [0 if dry else -1]
+    checked = [0]
+
+    def check_gathered(g, k):
+        """dry run: the tensor a step's collective delivered is [tiles of rank 0 | rank 1 | ...] of THAT step (ragged counts, lag 0 / 1)"""
+        if not dry or g is None:
+            return
+        assert g.shape[0] == sum(counts), (g.shape, counts)
+        o = 0
+        for r, c in enumerate(counts):
+            assert bool((g[o:o + c].float() == float(r) + float(k % 64)).all()), (r, k, g[o:o + c].flatten()[:4])
+            o += c
+        checked[0] += 1
 
     def step(marks=None):
         """marks: optional list receiving 4 marks (start, ViT+projector done, all-gather done, MSDA done); with marks the
@@ -466,15 +573,19 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
                 msda_calls(res)
         if dry:
             tokens = torch.full(tok_shape, float(rank), dtype=torch.bfloat16)
+            if step_no[0] >= 0:
+                tokens = tokens + float(step_no[0] % 64)    # (dry run: every step's tokens are recognisable, see `checked`)
+                step_no[0] += 1
         else:
             out = enc(pixels, output_hidden_states=True)
             tokens = bridge.project_hidden_state(out.hidden_states[-2], ivit)
         if marks is not None:
             ev()
         # the token all-gather (RCCL over xGMI, its own stream) overlaps the det-head MSDA kernels of this step
-        handle = all_gather_visual_tokens(tokens, counts=[tokens.shape[0]] * world, async_op=True, algo=args.allgather)
+        handle = all_gather_visual_tokens(tokens, counts=counts, async_op=True, algo=args.allgather)
         if marks is not None:
             gathered, _ = handle.wait()
+            check_gathered(gathered, step_no[0] - 1)
             ev()
         if side is None:
             msda_calls(res)
@@ -482,10 +593,13 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
             if lag[0] and world > 1:
                 # software pipeline across steps: this step's collective is waited for one step later (before the next one is
                 # launched), so it overlaps the NEXT step's encoder as well; the last one is drained before the timed region ends
-                prev, pending[0] = pending[0], handle
-                gathered = prev.wait()[0] if prev is not None else None
+                prev, pending[0] = pending[0], (handle, step_no[0] - 1)
+                gathered = prev[0].wait()[0] if prev is not None else None
+                if prev is not None:
+                    check_gathered(gathered, prev[1])
             else:
                 gathered, _ = handle.wait()
+                check_gathered(gathered, step_no[0] - 1)
         if side is not None:
             main.wait_stream(side)
         if marks is not None:
@@ -495,7 +609,7 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
 
     def drain():
         if pending[0] is not None:
-            pending[0].wait()
+            check_gathered(pending[0][0].wait()[0], pending[0][1])
             pending[0] = None
 
     def timed(n_steps, lag_steps):
@@ -522,7 +636,23 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
         # headline: the collective of a step is waited for INSIDE the step (lag 0: its cost is fully visible); for N > 1 the
         # pipelined schedule (lag 1: waited for one step later, overlapping the next encoder) is timed as well, same steps
         headline_lag = args.allgather_lag if world > 1 else 0
+        sampler = ClockSampler(dev) if (not dry and rank == 0) else None
+        sysfs = sampler is not None and sampler.has_sysfs()
+        if sysfs:
+            sampler.start(True)
         dt = timed(args.steps, headline_lag)
+        clocks = sampler.stop() if sysfs else None
+        if sampler is not None and clocks is None:
+            # no hwmon files on this box: rocm-smi over a SECOND, untimed run of the same steps (>= 1.5 s of them)
+            sampler.start(False)
+            t_end = time.perf_counter() + 1.5
+            while time.perf_counter() < t_end:
+                step()
+                sync()
+            drain()
+            clocks = sampler.stop()
+            if clocks is not None:
+                clocks["note"] = "sampled over an untimed repetition of the same steps right after the timed region"
         dt_alt = timed(args.steps, 1 - headline_lag) if world > 1 else None
         # per-phase times (outside the timed region): 3 instrumented steps, median per rank, max over ranks
         ph = []
@@ -547,7 +677,10 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
                 step()       # (all ranks run the same number of collectives)
         drain()
     red = torch.tensor([dt, ph[0], ph[1], ph[2], dt_alt if dt_alt is not None else 0.0], device=None if dry else dev, dtype=torch.float64)
+    per_rank = [red.clone()]
     if world > 1:
+        per_rank = [torch.empty_like(red) for _ in range(world)]
+        dist.all_gather(per_rank, red)            # every rank's own clock and phases: the first SCALE run explains itself
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     dt = float(red[0].item())
     if rank != 0:
@@ -557,7 +690,7 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
         "ms_per_step": dt / args.steps * 1e3,
         "config": {"workload": ("internvit6b_448_5tiles+pixelshuffle+internvl_mlp+msda_cfg4" if ivit else
                                 "vitl14_336_5tiles+mlp2x_gelu+msda_cfg4") + ("  [DRY RUN: kernels stubbed, CPU / gloo plumbing only]" if dry else ""),
-                   "images_per_gpu": IMAGES_PER_RANK, "tiles_per_image": TILES_PER_IMAGE, "image": "1336x1336",
+                   "images_per_gpu": IMAGES_PER_RANK, "tiles_per_image": TILES_PER_IMAGE if not args.ragged_tiles else "1-7 (any-res pattern; NOT the headline workload)", "image": "1336x1336",
                    "vit": "InternViT-6B 48L bf16 (448^2 tiles)" if ivit else "ViT-L/14-336 24L bf16",
                    "bridge": "pixel_shuffle + internvl_mlp 12800->4096->4096" if ivit else "mlp2x_gelu 1024->4096->4096",
                    "msda": "B8 M8 D32 L4 P4 168^2..21^2 fp32, 6x Lq=37485 + 6x Lq=900 (3 rotating value buffers)",
@@ -565,11 +698,18 @@ def run_workload(args, workload, dev, rank, world, dist, dry):
                    "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                    "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else "none"),
                    "allgather": args.allgather, "allgather_lag_steps": headline_lag,
+                   "tiles_per_rank": counts, "ragged_tiles": bool(args.ragged_tiles),
                    "streams": ("vit+projector | msda (side stream; cross-batch pipelining)" if args.msda_stream else "single") +
                               ("" if args.encoder_chunks <= 1 else f"; vit tiles as {args.encoder_chunks} chunks on separate streams")},
         "phases_ms": {"vit_projector": float(red[1].item()), "token_allgather": float(red[2].item()), "msda_12_calls": float(red[3].item()),
                       "note": "3 instrumented steps after the timed region (collective waited for before the MSDA calls), median per rank, max over ranks"},
+        "per_rank": [{"rank": r, "timed_s": float(v[0].item()), "vit_projector_ms": float(v[1].item()), "token_allgather_ms": float(v[2].item()),
+                      "msda_12_calls_ms": float(v[3].item()), "tiles": counts[r]} for r, v in enumerate(per_rank)],
     }
+    if dry:
+        rec["dry_run_collectives_checked"] = checked[0]
+    if not dry:
+        rec["clocks"] = clocks
     if world > 1:
         alt = float(red[4].item())
         rec["allgather_lag_alt"] = {"allgather_lag_steps": 1 - headline_lag, "value": world * IMAGES_PER_RANK * args.steps / alt,
@@ -619,6 +759,9 @@ def main():
                     help="token all-gather: RCCL all_gather_into_tensor (default) or batched point-to-point to all peers at once")
     ap.add_argument("--encoder-chunks", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="0 / 1 (default): one launch sequence; k: the tiles as k chunks on k streams (measured slower)")
+    ap.add_argument("--ragged-tiles", action="store_true",
+                    help="any-res batch: the world x 8 images get 1-7 tiles each and are dealt to the ranks by tile count "
+                         "(dist.shard_images); exercises ragged shards in the token all-gather.  Not the headline workload")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check (no GPU, gloo): launcher respawn, rank mapping, process group, lagged collective + drain, "
                          "phases, JSON -- with the kernels stubbed out in the bench only; the line says so and is NOT a measurement")

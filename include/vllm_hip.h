@@ -23,7 +23,11 @@
 extern "C" {
 #endif
 
-#define VLLM_ABI_VERSION 1
+/* Bumped whenever a struct layout or an entry point's meaning changes.  2 (round 4): VllmVitLayer grew by six pointers
+ * (an ARRAY of these is passed, so the stride changed) and VllmMsdaLayerDesc got `geometry` / `reserved0` in front of its
+ * pointers -- a caller built against version 1 must not run against this library: check vllm_abi_version() == VLLM_ABI_VERSION
+ * at load time and the vllm_*_sizeof() of every descriptor it fills. */
+#define VLLM_ABI_VERSION 2
 
 #define VLLM_OK 0
 #define VLLM_EINVAL (-1)   /* bad argument (shape / alignment / unsupported size) */

@@ -41,3 +41,24 @@ def test_bench_dry_run_single_rank_and_direct_allgather():
     rec = _run("--gpus", "2", "--allgather", "direct", "--allgather-lag", "1")
     assert rec["config"]["allgather"] == "direct" and rec["config"]["allgather_lag_steps"] == 1
     assert rec["allgather_lag_alt"]["allgather_lag_steps"] == 0
+
+
+def test_bench_dry_run_world_4_and_8_ragged_shards_both_algorithms_both_lags():
+    """the multi-GPU path at the world sizes the driver's SCALE run uses, on gloo: ragged tile counts (1-7
+    tiles per image dealt to the ranks by dist.shard_images), the collective waited for inside the step (lag 0) and one step
+    later (lag 1), RCCL-style collective and direct all-peers point-to-point.  In a dry run every step's tokens carry (rank,
+    step), and bench.py checks every gathered tensor slice by slice: `dry_run_collectives_checked` counts them."""
+    for world, algo, lag in ((4, "collective", 0), (4, "direct", 1), (8, "collective", 1), (8, "direct", 0)):
+        rec = _run("--gpus", str(world), "--ragged-tiles", "--allgather", algo, "--allgather-lag", str(lag))
+        cfg = rec["config"]
+        assert rec["n_gpus"] == world and cfg["rccl_ranks"] == world and cfg["allgather"] == algo and cfg["allgather_lag_steps"] == lag
+        counts = cfg["tiles_per_rank"]
+        assert len(counts) == world and len(set(counts)) > 1 and max(counts) - min(counts) <= 2   # ragged, balanced by tile count
+        assert sum(counts) == sum(1 + (i * i + 2 * i + 1) % 7 for i in range(world * 8))
+        # every rank reports its own clock and phases
+        assert [r["rank"] for r in rec["per_rank"]] == list(range(world))
+        assert [r["tiles"] for r in rec["per_rank"]] == counts
+        assert all(r["timed_s"] > 0 for r in rec["per_rank"])
+        # warm-up 1 + 2 timed steps x 2 schedules + 3 phase steps = 8 collectives, every one checked on rank 0
+        assert rec["dry_run_collectives_checked"] == 8, rec["dry_run_collectives_checked"]
+        assert rec["allgather_lag_alt"]["allgather_lag_steps"] == 1 - lag

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _lib.parse_header() if not hasattr(raw, n)]
     assert not missing, missing
     L = _lib.lib()
-    assert L.vllm_abi_version() == 1
+    assert L.vllm_abi_version() == _lib.header_abi_version() == 2   # (2: round-4 bump for the round-3 struct changes)
 
 
 def test_no_undeclared_exports():

@@ -56,6 +56,14 @@ def parse_header(path: str = HEADER):
     return protos
 
 
+def header_abi_version(path: str = HEADER) -> int:
+    """VLLM_ABI_VERSION of include/vllm_hip.h (the mirrors below are written against THIS header)."""
+    m = re.search(r"^#define\s+VLLM_ABI_VERSION\s+(\d+)", open(path).read(), flags=re.M)
+    if not m:
+        raise RuntimeError("include/vllm_hip.h: VLLM_ABI_VERSION not found")
+    return int(m.group(1))
+
+
 def lib():
     """Load (once) and return the shared library.  Fails loudly when it has not been built."""
     global _lib
@@ -75,8 +83,10 @@ def lib():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.vllm_abi_version() != 1:
-        raise RuntimeError("libvllm_hip.so ABI version mismatch")
+    want = header_abi_version()
+    if L.vllm_abi_version() != want:
+        raise RuntimeError(f"libvllm_hip.so ABI version {L.vllm_abi_version()} != header's VLLM_ABI_VERSION {want}: rebuild "
+                           "(make -C visionllm_amd/csrc)")
     _lib = L
     return L
 

@@ -122,7 +122,7 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.scale = scale; a.res = res;
         a.M = (int)M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.P = 0; a.mt = a.nt = 0; a.xP = 0;
         a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
-        if (a.variant == 1) a.variant = 0;   // (a forced 128x128 kernel cannot fold)
+        if (a.variant == 1 || a.variant == 4) a.variant = 0;   // (a forced 128x128 kernel / the 32x32x16 variant cannot fold)
         a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ntC; a.ln_cols = C; a.ln_rms = clip ? 0 : 1; a.ln_eps = d->eps;
         a.ln_colsum = colsum; a.ln_bias = bias_ln;
         return gemm_bf16_launch(epi, a, st);
