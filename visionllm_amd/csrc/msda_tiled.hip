@@ -337,6 +337,7 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
 // the phase clock, 8 generation 4 / 560-pixel windows / 2 blocks per CU, 9 generation 4 / 360 / 3 (the round-1 default),
 // 10-14 generation 6 (10 / 14 phase clock, 11-13 gather / staging variants), 15 generation 7, 16 generation 7 + phase clock,
 // 17 generation 6, 18 generation 8 (two teams half a period apart; = automatic on nested maps), 19 generation 8 + phase clock.
+// (Generation 9 -- eight waves, two per SIMD, software-pipelined gather: correct, 508 vs 458 us -- is tools/experiments/msda_tiled9.hip.)
 // Automatic (1): generation 8 (msda_tiled8.hip: pyramid items, two teams of six waves half a period apart) does the work when the
 // level maps are nested halves -- it checks that on the device, from the shape tensor, and returns at once otherwise -- and the
 // generation-4 launch behind it skips such maps, so exactly one of the two runs whatever the geometry, without a host

@@ -206,15 +206,18 @@ __global__ __launch_bounds__(768, 1) void msda_fwd_tiled8_kernel(
         if (!(T8_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
                      : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4) :: "memory"); \
         if (T8_ABL & 1) { acc[0] += a1[0] + a2[1] + a3[2] + a4[3] + e1; acc[4] += c1[0] + c2[1] + c3[2] + c4[3] + e2 + e3 + e4; } else \
-        _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                       \
-            float2_t t = {acc[c], acc[c + 1]};                                                                   \
-            t = t6_fma2(e1, (float2_t){a1[c], a1[c + 1]}, t); t = t6_fma2(e2, (float2_t){a2[c], a2[c + 1]}, t);  \
-            t = t6_fma2(e3, (float2_t){a3[c], a3[c + 1]}, t); t = t6_fma2(e4, (float2_t){a4[c], a4[c + 1]}, t);  \
-            acc[c] = t.x; acc[c + 1] = t.y;                                                                      \
-            float2_t u = {acc[4 + c], acc[5 + c]};                                                               \
-            u = t6_fma2(e1, (float2_t){c1[c], c1[c + 1]}, u); u = t6_fma2(e2, (float2_t){c2[c], c2[c + 1]}, u);  \
-            u = t6_fma2(e3, (float2_t){c3[c], c3[c + 1]}, u); u = t6_fma2(e4, (float2_t){c4[c], c4[c + 1]}, u);  \
-            acc[4 + c] = u.x; acc[5 + c] = u.y;                                                                  \
+        {   /* four independent chains, interleaved corner by corner (round 4: a chain at a time every packed multiply-add   */ \
+            /* waits for the one in front of it); per channel the corners are added in the same order as before: same bits */ \
+            float2_t t0 = {acc[0], acc[1]}, t1 = {acc[2], acc[3]}, u0 = {acc[4], acc[5]}, u1 = {acc[6], acc[7]};             \
+            t0 = t6_fma2(e1, (float2_t){a1[0], a1[1]}, t0); u0 = t6_fma2(e1, (float2_t){c1[0], c1[1]}, u0);                  \
+            t1 = t6_fma2(e1, (float2_t){a1[2], a1[3]}, t1); u1 = t6_fma2(e1, (float2_t){c1[2], c1[3]}, u1);                  \
+            t0 = t6_fma2(e2, (float2_t){a2[0], a2[1]}, t0); u0 = t6_fma2(e2, (float2_t){c2[0], c2[1]}, u0);                  \
+            t1 = t6_fma2(e2, (float2_t){a2[2], a2[3]}, t1); u1 = t6_fma2(e2, (float2_t){c2[2], c2[3]}, u1);                  \
+            t0 = t6_fma2(e3, (float2_t){a3[0], a3[1]}, t0); u0 = t6_fma2(e3, (float2_t){c3[0], c3[1]}, u0);                  \
+            t1 = t6_fma2(e3, (float2_t){a3[2], a3[3]}, t1); u1 = t6_fma2(e3, (float2_t){c3[2], c3[3]}, u1);                  \
+            t0 = t6_fma2(e4, (float2_t){a4[0], a4[1]}, t0); u0 = t6_fma2(e4, (float2_t){c4[0], c4[1]}, u0);                  \
+            t1 = t6_fma2(e4, (float2_t){a4[2], a4[3]}, t1); u1 = t6_fma2(e4, (float2_t){c4[2], c4[3]}, u1);                  \
+            acc[0] = t0.x; acc[1] = t0.y; acc[2] = t1.x; acc[3] = t1.y; acc[4] = u0.x; acc[5] = u0.y; acc[6] = u1.x; acc[7] = u1.y; \
         }                                                                                                        \
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),   \
                           "+v"(acc[6]), "+v"(acc[7]));                                                           \
