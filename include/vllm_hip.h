@@ -41,16 +41,19 @@ const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped (Lq == S) MSDA forward kernel, same results to fp32
- * rounding: 0 plain gather kernel; 1 automatic (default): generation 7 (msda_tiled7.hip: pyramid items, software pipeline
+ * rounding: 0 plain gather kernel; 1 automatic (default): generation 8 (msda_tiled8.hip: pyramid items, two teams of waves half a period apart;
+ * round 2: generation 7, one software pipeline
  * across items) when the level maps form an exact 2x pyramid -- decided on the device, no host sync -- else generation 4;
  * 2 generation 4 with 8 waves per block; 3 generation 2; 5 generation 4 with the phase clock (vllm_debug_counters);
  * 8 generation 4, 560-pixel windows, 2 blocks per CU; 9 generation 4, 360 pixels, 3 blocks per CU (the round-1 default);
- * 10-14 generation 6 (msda_tiled6.hip; 10 / 14 with phase clock, 11-13 gather / staging variants); 15 generation 7;
- * 16 generation 7 with the phase clock; 17 generation 6.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
+ * 10-14 generation 6 (msda_tiled6.hip; 10 / 14 with phase clock, 11-13 gather / staging variants); 17 generation 6; 18 generation 8
+ * (msda_tiled8.hip, what "automatic" runs on nested level maps since round 3), 19 generation 8 with the phase clock.  15 / 16
+ * (generation 7) are rejected since round 4: that kernel is tools/experiments/msda_tiled7.hip.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
  * kernel, 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the 8-phase kernel's epilogue goes 0 through LDS
  * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).
  * "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted
- * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).
+ * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).  (Bit 6 selected round 3's
+ * hand-placed schedule, exactly as fast: tools/experiments/attn2.hip since round 4; the bit is ignored.)
  * "dcnv3_tiled": DCNv3 forward for fp32, group channels 16 / 32, <= 9 points: 1 (default) the pipelined LDS-tiled kernel
  * (dcnv3_pipe.hip), 3 the two-blocks-per-CU LDS-tiled kernel (dcnv3_tiled.hip), 0 the gather kernel (same results to fp32
  * rounding); 2 / 4 = 1 / 3 with the phase clock (vllm_debug_counters then reads IT).

@@ -239,7 +239,7 @@ def test_attention_lane_swaps_read_both_results(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in ("attn.hip", "attn2.hip"):
+    for name in ("attn.hip",):   # (attn2.hip left the library in round 4: tools/experiments/)
         src = os.path.join(root, "visionllm_amd", "csrc", name)
         out = tmp_path / (name + ".s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"), "-S",

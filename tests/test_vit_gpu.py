@@ -457,7 +457,7 @@ def _attn_ref(qkv, H, D, scale):
     return V.attention_core(q, k, v, scale).reshape(B, S, H, D)
 
 
-@pytest.fixture(params=[32, 64], ids=["sched_auto", "sched2"])
+@pytest.fixture(params=[32], ids=["sched_auto"])   # (schedule 2 = tools/experiments/attn2.hip since round 4: exactly as fast, not in the library)
 def attn_sched(request):
     """Run a test under the automatic schedule and under schedule 2 (attn2.hip) explicitly."""
     old = _lib.set_option("attn_variant", request.param)
@@ -503,7 +503,7 @@ def test_attention_online_softmax_rescale_branch(D, attn_sched):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
-@pytest.mark.parametrize("variant", [0, 2, 6, 8, 10, 14, 3, 18, 64, 192, 320, 448, 576, 960, 1088, 1216])   # 18: no padding trim; 64 | v << 7: schedule 2 (v bit 3: one item per block)
+@pytest.mark.parametrize("variant", [0, 2, 3, 18])   # plain, deferred rescale (the default's), software-pipelined K, no padding trim (round 4: the variant list is cut to what differs structurally; the bit combinations ran green through round 3)
 @pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
 def test_attention_schedule_variants(variant, D, S):
     """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""

@@ -36,6 +36,9 @@
 #ifndef T9_WAITCNT    // s_waitcnt lgkmcnt(N) that releases the older register set: 8 by construction; 7 = experiment (race screen)
 #define T9_WAITCNT 8
 #endif
+#ifndef T9_TW         // waves per team: 4 (8 waves, 2 per SIMD, 3 passes of 64 slots) or 6 (12 waves, 3 per SIMD, 2 passes of 96 slots:
+#define T9_TW 4       // generation 8's shape with this file's straight-line halves and pipelined gather)
+#endif
 #ifndef T9_GPRIO      // s_setprio of a wave while it gathers
 #define T9_GPRIO 2
 #endif
@@ -108,12 +111,13 @@ __device__ __forceinline__ void t9_fma(T9Acc &a, const T9Set &s, float e1, float
 
 // EXACT: the level maps are exact halves (H_l << l == H_0): sizes by shifts; otherwise nested maps, sizes from LDS (generation 8).
 template <int WIN, bool PROF, bool EXACT>
-__global__ __launch_bounds__(512, 1) void msda_fwd_tiled9_kernel(
+__global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, int B, int S, int M, int L, int Lq,
     float *__restrict__ out, uint16_t *__restrict__ out16, int hinted)
 {
-    constexpr int D = 32, PT = 4, NW = 8, TW = 4, NP = 3, THREADS = NW * 64, R = WIN;
+    constexpr int D = 32, PT = 4, TW = T9_TW, NW = 2 * TW, NP = TW == 4 ? 3 : 2, THREADS = NW * 64, R = WIN;
+    static_assert(TW == 4 || TW == 6, "teams of four or six waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_box = reinterpret_cast<int *>(smem + (T6_ZPX + R + T6_SLACK) * 128);   // [2 teams][4 levels][4]: min hl, min -hl, min wl, min -wl
     int *s_used = s_box + 32;                                                      // [2 teams]: pixels of the arena the team's item occupies
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(512, 1) void msda_fwd_tiled9_kernel(
                     }
                     store_out(acc, qokc[0], prc[0]);
 #define T9_TAKE(P_) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { w1[0][i] = w1[P_][i]; w2[0][i] = w2[P_][i]; w3[0][i] = w3[P_][i]; w4[0][i] = w4[P_][i]; o[0][i] = o[P_][i]; } qokc[0] = qokc[P_]; prc[0] = prc[P_]; }
-                    if (p == 0) T9_TAKE(1) else if (p == 1) T9_TAKE(2)
+                    if (p == 0) T9_TAKE(1) else if (NP > 2 && p == 1) T9_TAKE(NP > 2 ? 2 : 1)
 #undef T9_TAKE
                 }
                 T9_TICK(6)
@@ -643,7 +647,7 @@ int t9_go(const float *value, const int64_t *shapes, const int64_t *lsi, const f
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled9_kernel<WIN, PROF, EXACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    VLLM_LAUNCH((msda_fwd_tiled9_kernel<WIN, PROF, EXACT>), dim3((cus / 8) * 8), dim3(512), lds, st, value, shapes, lsi, loc, attw,
+    VLLM_LAUNCH((msda_fwd_tiled9_kernel<WIN, PROF, EXACT>), dim3((cus / 8) * 8), dim3(T9_TW * 128), lds, st, value, shapes, lsi, loc, attw,
                 B, S, M, L, Lq, out, out16, hinted);
     VLLM_CHECK_LAUNCH("msda_fwd_tiled9_kernel");
     return VLLM_OK;

@@ -6,7 +6,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from msda_inputs import make_inputs
 from test_msda_gpu import PYRAMIDS
 from visionllm_amd import _lib, ms_deform_attn as A
+import ctypes
 dev = "cuda:0"
+SIDE = os.environ.get("MSDA9_LIB")     # a side build of tools/experiments/msda_tiled9.hip (tools/msda9_variants.sh) instead of a library mode
+side = None
+if SIDE:
+    side = ctypes.CDLL(SIDE)
+    side.t9_abl_run.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 mode_id = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for name in sorted(PYRAMIDS):
@@ -22,12 +28,22 @@ for name in sorted(PYRAMIDS):
         elif mode == "uniform":
             g["loc"] = (rng.random(g["loc"].shape, dtype=np.float32) * 1.1 - 0.05).astype(np.float32)
         fresh = os.environ.get("FRESH", "1") == "1"
+        use_side = [False]
         t = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
         def run():
             tt = {k: torch.from_numpy(v).to(dev) for k, v in g.items()} if fresh else t     # (as the tests do: new tensors, cold caches)
+            if side is not None and use_side[0]:
+                Bv, Sv, Mv, Dv = tt["value"].shape
+                o = torch.empty(Bv, tt["loc"].shape[1], Mv * Dv, device=dev)
+                rc = side.t9_abl_run(tt["value"].data_ptr(), tt["shapes"].data_ptr(), tt["lsi"].data_ptr(), tt["loc"].data_ptr(), tt["attw"].data_ptr(),
+                                     Bv, Sv, Mv, tt["loc"].shape[3], tt["loc"].shape[1], o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+                return o
             return A.ms_deform_attn_forward(tt["value"], tt["shapes"], tt["lsi"], tt["loc"], tt["attw"], 64)
+        use_side = [False]
         _lib.set_option("msda_tiled", 0); ref = run()
         _lib.set_option("msda_tiled", mode_id)
+        use_side[0] = True
         first = run(); bad = 0; worst = 0.0; where = {}
         for it in range(N):
             o = run()

@@ -373,11 +373,10 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     const long groups = ((long)a.B * a.H + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
     const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    // attn_variant: 32 = automatic; bit 6 (64) selects schedule 2 (attn_fwd2_kernel) with its VAR in bits 7-9; otherwise
-    // bits 0-3 are attn_fwd_kernel's VAR and bit 4 switches the padding trim off
+    // attn_variant: 32 = automatic; bits 0-3 are attn_fwd_kernel's VAR, bit 4 switches the padding trim off.  (Schedule 2 -- the
+    // hand-placed instruction stream of round 3, exactly as fast -- is tools/experiments/attn2.hip since round 4.)
     int var = attn_variant();
     if (var & 32) var = 2;
-    if (var & 64) return attn_fwd2_launch(a, D, (var >> 7) & 15, st);
     a.no_trim = (var >> 4) & 1;
     var &= 15;
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)

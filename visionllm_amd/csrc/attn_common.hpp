@@ -1,4 +1,4 @@
-// Shared by the attention kernels (attn.hip: round-1/2 schedule; attn2.hip: round-3 schedule).
+// Shared by the attention kernels (attn.hip; tools/experiments/attn2.hip: the round-3 hand-placed schedule, same speed).
 #pragma once
 #include "common.hpp"
 #include "kernels.hpp"
@@ -34,6 +34,5 @@ __device__ __forceinline__ float halves_sum(float x)
 }
 
 
-int attn_fwd2_launch(AttnArgs a, int D, int var2, hipStream_t st);   // attn2.hip (a.nqt filled by the caller)
 
 }  // namespace vllm

@@ -324,9 +324,6 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                        const float *attw, int B, int S, int M, int L, int Lq, float *out, int skip_pyramid,
                        hipStream_t st);   // msda_tiled4.hip
 bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
-int msda_tiled7_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16 = nullptr,
-                       int hinted = 0);   // msda_tiled7.hip
 int msda_tiled8_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted,
                        int which);   // msda_tiled8.hip
@@ -335,13 +332,14 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
 
 // "msda_tiled": 0 gather kernel, 1 automatic (default), 2 generation 4 with 8 waves, 3 generation 2, 5 generation 4 with
 // the phase clock, 8 generation 4 / 560-pixel windows / 2 blocks per CU, 9 generation 4 / 360 / 3 (the round-1 default),
-// 10-14 generation 6 (10 / 14 phase clock, 11-13 gather / staging variants), 15 generation 7, 16 generation 7 + phase clock,
+// 10-14 generation 6 (10 / 14 phase clock, 11-13 gather / staging variants); (15 / 16, generation 7, left the library in round 4:
+// tools/experiments/msda_tiled7.hip),
 // 17 generation 6, 18 generation 8 (two teams half a period apart; = automatic on nested maps), 19 generation 8 + phase clock.
 // (Generation 9 -- eight waves, two per SIMD, software-pipelined gather: correct, 508 vs 458 us -- is tools/experiments/msda_tiled9.hip.)
 // Automatic (1): generation 8 (msda_tiled8.hip: pyramid items, two teams of six waves half a period apart) does the work when the
 // level maps are nested halves -- it checks that on the device, from the shape tensor, and returns at once otherwise -- and the
 // generation-4 launch behind it skips such maps, so exactly one of the two runs whatever the geometry, without a host
-// synchronisation.  15 / 16: generation 7 (the round-2 default: one 12-wave software pipeline across items) in its place.
+// synchronisation.
 int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *attw, int B, int S, int M, int L, int Lq, int P, float *out, hipStream_t st, uint16_t *out16,
                       int *wrote16, int geometry)
@@ -354,14 +352,12 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
     // geometry (VLLM_GEO_*): what the HOST knows about the level maps.  UNKNOWN: both kernels are enqueued and the device
     // picks (no host synchronisation; one ~5 us empty launch); PYRAMID / GENERAL: exactly one launch.
-    if ((mode == 1 || mode == 15 || mode == 16 || mode == 18 || mode == 19) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
+    if ((mode == 1 || mode == 18 || mode == 19) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
         geometry != VLLM_GEO_GENERAL) {
         if (out16 && wrote16) *wrote16 = 1; else out16 = nullptr;
         // host hint: PYRAMID = exact halves, NESTED = halves rounded either way (one launch each); UNKNOWN: the device decides
         const int hinted = geometry == VLLM_GEO_PYRAMID || geometry == VLLM_GEO_NESTED;
-        if (mode == 15 || mode == 16) {
-            if (int e = msda_tiled7_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 16, st, out16, hinted)) return e;
-        } else {
+        {
             const int which = geometry == VLLM_GEO_PYRAMID ? 1 : geometry == VLLM_GEO_NESTED ? 2 : 3;
             if (int e = msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 19, st, out16, hinted, which)) return e;
         }
