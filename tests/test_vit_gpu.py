@@ -262,14 +262,26 @@ def test_gemm256_persistent_schedule(M, N, K, epi, force, pad, bias):
     b = bf(torch.randn(N, device=DEV)) if bias else None
     ys = []
     before = L.vllm_gemm_persistent_launches()
-    for flags in (force, force, force | 0x1000):
-        y = torch.full((M + 300, ldy), 7.0, dtype=torch.bfloat16, device=DEV)     # canary rows (a whole tile's worth) and, strided cases, columns
-        _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b) if bias else None, P(y), M, N, K, ldx, ldw, ldy, epi | flags, None, None, 0, 0, stream()))
-        ys.append(y)
+    # round 4: the tile ORDER of the persistent walk -- dense XCD order (0), banded with 3 / 4 / 8 row panels per band, automatic
+    # (-1) -- changes which CU computes a tile, never a tile's arithmetic: every order must equal one workgroup per tile bit for bit
+    orders = (-1, -1, 0, 3, 4, 8)
+    try:
+        for rb in orders:
+            _lib.set_option("gemm_tile_rb", rb)
+            y = torch.full((M + 300, ldy), 7.0, dtype=torch.bfloat16, device=DEV)     # canary rows (a whole tile's worth) and, strided cases, columns
+            _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b) if bias else None, P(y), M, N, K, ldx, ldw, ldy, epi | force, None, None, 0, 0, stream()))
+            ys.append(y)
+    finally:
+        _lib.set_option("gemm_tile_rb", -1)
+    y = torch.full((M + 300, ldy), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b) if bias else None, P(y), M, N, K, ldx, ldw, ldy, epi | force | 0x1000, None, None, 0, 0, stream()))
+    ys.append(y)
     torch.cuda.synchronize()
-    assert L.vllm_gemm_persistent_launches() - before == 2, "the persistent schedule was not taken"
+    assert L.vllm_gemm_persistent_launches() - before == len(orders), "the persistent schedule was not taken"
     assert torch.equal(ys[0], ys[1]), "persistent schedule: run-to-run difference"
-    assert torch.equal(ys[0], ys[2]), "persistent schedule differs from one workgroup per tile"
+    for i, rb in enumerate(orders[2:], start=2):
+        assert torch.equal(ys[0], ys[i]), f"persistent schedule: tile order {rb} changes the result"
+    assert torch.equal(ys[0], ys[-1]), "persistent schedule differs from one workgroup per tile"
     assert (ys[0][M:] == 7.0).all() and (ys[0][:, N:] == 7.0).all(), "wrote outside the output block"
     rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).to(DEV)             # first and last row tiles against fp64
     z = x[rows, :K].double() @ w[:, :K].double().t() + (b.double() if bias else 0.0)

@@ -111,10 +111,31 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
     const int T = a.mt * a.nt, G = gridDim.x;
     constexpr int BM = 64 * MT, HM = 32 * MT;     // block rows; rows of an A half
 
-    // dense tile order of gemm256.hip (XCD = tile & 7 owns a panel): tile -> first row / column
+    // tile -> first row / column.  tile_rb == 0: the dense tile order of gemm256.hip (XCD = tile & 7 owns a panel).
+    // tile_rb = RB > 0 (round 4): BANDED order.  The tiles are enumerated band by band (RB row panels), column by column inside a
+    // band, and the 32 blocks of an XCD take 32 CONSECUTIVE tiles of that enumeration in every full round -- an RB x (32 / RB)
+    // rectangle of the tile grid: its 32 CUs, which run in step, share RB activation panels and 32 / RB weight tiles through the
+    // XCD's L2 (RB + 32 / RB operand streams per round instead of 1 + 32: in the dense order an XCD walks 32 different column
+    // tiles of ONE row panel, and every XCD streams the whole weight once per row panel -- 13.7 GB through the fabric per
+    // InternViT-6B fc1 launch against 1.39 GB of algorithmic bytes, profiles/pmc_traffic.json).  Same tiles, same arithmetic:
+    // bit-identical outputs.  The last, partial round keeps the enumeration order (tile = block index).
+    const int tile_rb = a.tile_rb;
+    const int full_tiles = (T / G) * G;
     auto coords = [&](int td, int &m0, int &n0) {
         int tm, tn;
-        if ((a.nt & 7) == 0) {
+        if (tile_rb > 0) {
+            int q = td;
+            if (td < full_tiles) {
+                const int cpx = G >> 3;                                  // blocks per XCD
+                const int rnd = td / G, rem = td - rnd * G;
+                q = ((rnd << 3) + (rem & 7)) * cpx + (rem >> 3);         // chunk (round, XCD) x position in the chunk
+            }
+            const int bs = tile_rb * a.nt;                                  // tiles per full band
+            const int band = q / bs, r = q - band * bs;
+            const int rows = min(tile_rb, a.mt - band * tile_rb);                 // (the last band may be shorter)
+            tn = r / rows;
+            tm = band * tile_rb + (r - tn * rows);
+        } else if ((a.nt & 7) == 0) {
             const int xcd = td & 7, s = td >> 3, npx = a.nt >> 3;
             tn = xcd + 8 * (s % npx);
             tm = s / npx;
@@ -601,8 +622,17 @@ bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
 static long g_p_launches = 0;   // (vllm_gemm_persistent_launches: tests assert the path they mean to cover ran)
 long gemm256p_launches() { return g_p_launches; }
 
-int gemm256p_launch(int epi, int MT, const GemmArgs &a, int cus, hipStream_t st)
+int gemm256p_launch(int epi, int MT, const GemmArgs &a_, int cus, hipStream_t st)
 {
+    GemmArgs a = a_;
+    {
+        // automatic (measured, tools/gemm_tile_order_ab.py, profiles/r04_gemm_tile_order.txt): bands of 4 row panels (4 x 8 tiles
+        // per XCD and round) from 32 column tiles on, bands of 8 (8 x 4) from 8 column tiles on, the dense order below that
+        // (N = 1024: 4 column tiles -- nothing to share)
+        const int e = gemm_tile_rb();   // -1: automatic
+        a.tile_rb = e >= 0 ? e : (a.nt >= 32 ? 4 : a.nt >= 8 ? 8 : 0);
+        if (a.tile_rb > 32 || (a.tile_rb > 0 && (cus & 7) != 0)) a.tile_rb = 0;
+    }
     ++g_p_launches;
     const long T = (long)a.mt * a.nt;
     const dim3 grid((unsigned)std::min<long>(T, cus)), block(P_THREADS);

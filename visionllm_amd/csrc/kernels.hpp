@@ -64,12 +64,15 @@ struct GemmArgs {
     //   mean += (mean_s - mean) * ln_cw[s];  M2 += M2_s + (mean_s - mean)^2 * ln_cc[s];   ln_inv_cols = 1 / ln_cols
     float ln_cw[4] = {0.f, 0.f, 0.f, 0.f}, ln_cc[4] = {0.f, 0.f, 0.f, 0.f}, ln_inv_cols = 0.f;
     int no_persist = 0;             // 1: one workgroup per tile even where the persistent schedule (gemm256p.hip) would take the GEMM
+    int tile_rb = 0;                // persistent schedule, tile order: 0 = the dense XCD order of gemm256.hip; RB > 0 = banded (launcher)
     unsigned long long *trace = nullptr;   // VLLM_GEMM_TRACE=<device address of 3 x 8192 uint64>: per block {start, end} in
                                            // 100 MHz s_memrealtime ticks + HW_ID (which CU), for tools/prof_gemm256.py
 };
 
 int gemm_direct_store();       // VLLM_GEMM_DIRECT_STORE / vllm_set_option("gemm_direct_store")
 int gemm_variant_override();   // VLLM_GEMM_VARIANT / vllm_set_option("gemm_variant")
+extern int g_gemm_tile_rb;
+int gemm_tile_rb();            // VLLM_GEMM_TILE_RB / vllm_set_option("gemm_tile_rb"): -1 automatic, 0 dense XCD order, RB > 0 banded
 int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio,
                                // bit3 asm tr-reads, bit4 no padding trim, 32 = automatic (default)
 int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")

@@ -49,6 +49,17 @@ int attn_variant()
     }
     return g_attn_variant;
 }
+// persistent GEMM tile order (gemm256p.hip): -1 automatic (default), 0 the dense XCD order, RB > 0 banded with RB row panels per band
+int g_gemm_tile_rb = -2;
+int gemm_tile_rb()
+{
+    if (g_gemm_tile_rb == -2) {
+        const char *e = getenv("VLLM_GEMM_TILE_RB");
+        g_gemm_tile_rb = e ? atoi(e) : -1;
+        if (g_gemm_tile_rb < -1 || g_gemm_tile_rb > 32) g_gemm_tile_rb = -1;
+    }
+    return g_gemm_tile_rb;
+}
 int gemm_variant_override()
 {
     if (g_gemm_variant < 0) {
@@ -85,6 +96,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!strcmp(name, "msda_layer_fused")) { const int old = vllm::msda_layer_fused(); vllm::g_layer_fused = value != 0; return old; }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
     if (!strcmp(name, "attn_variant")) { const int old = vllm::attn_variant(); vllm::g_attn_variant = value & 0xffff; return old; }
+    if (!strcmp(name, "gemm_tile_rb")) { const int old = vllm::gemm_tile_rb(); vllm::g_gemm_tile_rb = (value < -1 || value > 32) ? -1 : value; return old; }
     if (!strcmp(name, "gemm_variant")) {
         const int old = vllm::gemm_variant_override();
         if (value < 0 || value > 4 || value == 3) { vllm::set_error("gemm_variant must be 0, 1, 2 or 4"); return VLLM_EINVAL; }
