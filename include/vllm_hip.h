@@ -206,6 +206,17 @@ int vllm_dcnv3_forward_f32(const float *input, const float *offset, const float 
 int vllm_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, int N, int H, int W, int G, int C,
                            int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, double offset_scale, double *out,
                            vllm_stream_t stream);
+/* Backward (round 4).  Replaces DCNv3.dcnv3_backward (ops_dcnv3/src/dcnv3.h:41-64, cuda/dcnv3_cuda.cu:92-174; kernels
+ * dcnv3_im2col_cuda.cuh:86-146, 279-857), called by DCNv3Function.backward (functions/dcnv3_func.py:51-59).
+ * grad_output [N, Ho, Wo, G*C]; grad_input [N, H, W, G*C] MUST BE ZERO-FILLED by the caller (the reference's host code allocates it
+ * with at::zeros_like; the sums arrive by floating-point atomics); grad_offset [N, Ho, Wo, G*kh*kw*2] and grad_mask
+ * [N, Ho, Wo, G*kh*kw] are written completely.  Any channel count (group channels 4 / 8 / 16 / 32 / 64: the vectorised kernel). */
+int vllm_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output, int N, int H, int W,
+                            int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float offset_scale,
+                            float *grad_input, float *grad_offset, float *grad_mask, vllm_stream_t stream);
+int vllm_dcnv3_backward_f64(const double *input, const double *offset, const double *mask, const double *grad_output, int N, int H, int W,
+                            int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, double offset_scale,
+                            double *grad_input, double *grad_offset, double *grad_mask, vllm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * f4. Region-encoder point sampling.

@@ -1,4 +1,4 @@
-"""ORACLE -- test infrastructure only.  ctypes front-end of oracle/dcnv3_oracle.c (DCNv3 forward) plus a torch
+"""ORACLE -- test infrastructure only.  ctypes front-end of oracle/dcnv3_oracle.c (DCNv3 forward + backward) plus a torch
 restatement of the reference's pure-PyTorch twin ``dcnv3_core_pytorch``
 (VisionLLMv2/visionllmv2/model/ops_dcnv3/functions/dcnv3_func.py:61-161), which is the path the reference runs on CPU."""
 import ctypes
@@ -37,6 +37,23 @@ def forward(inp, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group, group_chan
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     fn(p(inp), p(offset), p(mask), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw, sc, Ho, Wo, p(out))
     return out
+
+
+def backward(inp, offset, mask, grad_out, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale):
+    """-> (grad_input, grad_offset, grad_mask): the reference's dcnv3_col2im (dcnv3_im2col_cuda.cuh:86-146, 279-857) restated."""
+    dt = np.float64 if inp.dtype == np.float64 else np.float32
+    inp, offset, mask, grad_out = (np.ascontiguousarray(a, dt) for a in (inp, offset, mask, grad_out))
+    N, H, W, C = inp.shape
+    assert C == group * group_channels
+    Ho, Wo = out_size(H, W, kh, kw, sh, sw, ph, pw, dh, dw)
+    assert grad_out.shape == (N, Ho, Wo, C)
+    gi, go, gm = np.zeros_like(inp), np.empty_like(offset), np.empty_like(mask)
+    fn = lib().dcnv3_backward_f64 if dt == np.float64 else lib().dcnv3_backward_f32
+    sc = ctypes.c_double(offset_scale) if dt == np.float64 else ctypes.c_float(offset_scale)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    fn(p(inp), p(offset), p(mask), p(grad_out), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw, sc, Ho, Wo,
+       p(gi), p(go), p(gm))
+    return gi, go, gm
 
 
 def core_pytorch_twin(inp, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale):

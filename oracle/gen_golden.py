@@ -455,16 +455,31 @@ def gen_dcnv3():
         out64 = core(inp.double(), offset.double(), mask.double(), kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D,
                      offset_scale).detach()
         out32 = core(inp, offset, mask, kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D, offset_scale).detach()
+        # backward (round 4): autograd through the reference's twin, as its own test does (ops_dcnv3/test.py:94-160), with a random
+        # grad_output (its own generator: the forward tensors above keep their values) instead of ones
+        gen = torch.Generator().manual_seed(1000 + seed)
+        grad_out = torch.randn(out64.shape, generator=gen, dtype=torch.float64)
+        grads = {}
+        for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            a, b, c = (t.detach().to(dt).requires_grad_(True) for t in (inp, offset, mask))
+            core(a, b, c, kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D, offset_scale).backward(grad_out.to(dt))
+            grads[f"grad_input_{tag}"], grads[f"grad_offset_{tag}"], grads[f"grad_mask_{tag}"] = a.grad.numpy(), b.grad.numpy(), c.grad.numpy()
         np.savez_compressed(os.path.join(OUT, f"dcnv3_{name}.npz"), input=inp.numpy(), offset=offset.numpy(),
                             mask=mask.numpy(), out_f32=out32.numpy(), out_f64=out64.numpy(),
                             params=np.array([kh, kw, stride, stride, pad_h, pad_w, dil, dil, M, D], dtype=np.int64),
-                            offset_scale=np.array(offset_scale), torch_version=np.array(torch.__version__))
-        print(f"dcnv3_{name}: out {tuple(out64.shape)} f64[0,0,0,:3]={out64[0, 0, 0, :3].tolist()}")
+                            offset_scale=np.array(offset_scale), torch_version=np.array(torch.__version__),
+                            grad_out=grad_out.numpy(), **grads)
+        print(f"dcnv3_{name}: out {tuple(out64.shape)} f64[0,0,0,:3]={out64[0, 0, 0, :3].tolist()} |grad_offset| max {np.abs(grads['grad_offset_f64']).max():.3g}")
 
     case("kat_seed3", 2, 8, 8, 4, 16, 3, 3, 1, 1, 1, 1, 2.0, 3)
     case("stride2_dil2", 2, 11, 9, 2, 8, 3, 3, 2, 2, 2, 2, 1.0, 21, off_mag=3.0)
     # (the twin pads W by pad_h and H by pad_w, dcnv3_func.py:129-131, so it only works for pad_h == pad_w)
     case("k5x3_odd_channels", 1, 7, 10, 3, 5, 5, 3, 1, 1, 1, 1, 0.5, 22, off_mag=4.0)
+    # the reference's backward channel list (test.py:257-260: 1, 16, 30, 32, 64, 71, 1025) at its test geometry (N 2, 8x8, M 2);
+    # 16 / 32 / 64 are covered by the cases above and by the oracle on the GPU side, 1025 by the oracle only (fixture size)
+    case("bwd_c1", 2, 8, 8, 2, 1, 3, 3, 1, 1, 1, 1, 2.0, 31)
+    case("bwd_c30", 2, 8, 8, 2, 30, 3, 3, 1, 1, 1, 1, 2.0, 32)
+    case("bwd_c71", 2, 8, 8, 2, 71, 3, 3, 1, 1, 1, 1, 2.0, 33)
 
 
 def gen_point_sample():

@@ -150,3 +150,86 @@ def test_errors_and_module():
     assert sorted(k for k in mod.state_dict() if "dw_conv" not in k) == sorted([
         "center_feature_scale_proj_bias", "center_feature_scale_proj_weight", "input_proj.bias", "input_proj.weight",
         "mask.bias", "mask.weight", "offset.bias", "offset.weight", "output_proj.bias", "output_proj.weight"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 4: DCNv3 backward (dcnv3_col2im; DCNv3Function.backward, functions/dcnv3_func.py:51-59)
+BWD_CASES = CASES + ["dcnv3_bwd_c1.npz", "dcnv3_bwd_c30.npz", "dcnv3_bwd_c71.npz"]
+
+
+@pytest.mark.parametrize("name", BWD_CASES)
+def test_backward_vs_reference_autograd_golden(name):
+    """Gradients made by autograd through the reference's dcnv3_core_pytorch (the reference's own backward test, ops_dcnv3/test.py:94-235,
+    its thresholds rtol 1e-2 / atol 1e-3) -- through DCNv3Function (autograd) in fp64, and the raw entry point in fp32."""
+    g = load_golden(name)
+    a = _args(g)
+    t = lambda k, dt: torch.from_numpy(g[k]).to(dt).to(DEV)
+    inp, off, msk = (t(k, torch.float64).requires_grad_(True) for k in ("input", "offset", "mask"))
+    out = A.DCNv3Function.apply(inp, off, msk, *a, 2)
+    out.backward(t("grad_out", torch.float64))
+    for got, key in ((inp.grad, "grad_input_f64"), (off.grad, "grad_offset_f64"), (msk.grad, "grad_mask_f64")):
+        ref = g[key]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-2, atol=1e-3, err_msg=key)                   # the reference's bar
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * np.abs(ref).max() + 1e-12, err_msg=key)   # (fp32 reference points in the twin)
+    # fp64 kernel against the fp64 C oracle: the same arithmetic per (point, channel); sums in another order
+    d = lambda k: g[k].astype(np.float64)
+    oi, oo, om = O.backward(d("input"), d("offset"), d("mask"), d("grad_out"), *a)
+    for got, ref, key in ((inp.grad, oi, "grad_input"), (off.grad, oo, "grad_offset"), (msk.grad, om, "grad_mask")):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-10, atol=1e-12 * max(np.abs(ref).max(), 1e-30) + 1e-18, err_msg=key)
+    gi, go, gm = A.dcnv3_backward(t("input", torch.float32), t("offset", torch.float32), t("mask", torch.float32), *a,
+                                  t("grad_out", torch.float32), 2)
+    for got, key in ((gi, "grad_input_f64"), (go, "grad_offset_f64"), (gm, "grad_mask_f64")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-2, atol=1e-3, err_msg=key)                 # test.py:203-235 (float)
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=2e-3, atol=2e-5 * np.abs(g[key]).max(), err_msg=key)
+
+
+@pytest.mark.parametrize("N,H,W,G,C,k,s,p,d,scale", [
+    (2, 56, 56, 4, 16, 3, 1, 1, 1, 1.0),     # InternImage stage-1-like: group channels 16 (4 lanes per group)
+    (2, 42, 42, 5, 32, 3, 1, 1, 1, 1.0),     # group channels 32 (8 lanes)
+    (1, 20, 24, 3, 64, 3, 1, 1, 1, 1.0),     # 64 (16 lanes): the widest vectorised group
+    (1, 30, 41, 6, 20, 3, 2, 1, 1, 2.0),     # 20 channels: multiple of 4 but 5 lanes per group -> the generic kernel; strided, ragged map
+    (2, 17, 13, 3, 7, 5, 1, 2, 1, 0.7),      # odd channel count, 5x5
+    (1, 9, 9, 2, 8, 3, 1, 2, 2, 1.5),        # dilation 2, 2 lanes per group
+    (3, 4, 5, 1, 4, 1, 1, 0, 1, 1.0),        # 1x1 kernel, one lane per group
+    (2, 8, 8, 2, 1025, 3, 1, 1, 1, 2.0),     # the reference's gradcheck list ends with 1025 channels (test.py:257)
+])
+def test_backward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
+    """fp32 kernels against the fp32 C oracle: grad_offset / grad_mask per element (same terms, other summation order over the
+    group's channels), grad_input per element within the fp32 rounding of the sum of |terms| (the scatter order is the hardware's);
+    NaN / inf offsets are rejected points with zero gradients; two runs agree to the same bound."""
+    rng = np.random.default_rng(N * 100 + H + C)
+    Ho, Wo = O.out_size(H, W, k, k, s, s, p, p, d, d)
+    inp = rng.standard_normal((N, H, W, G * C)).astype(np.float32)
+    off = (rng.standard_normal((N, Ho, Wo, G * k * k * 2)) * 2.5).astype(np.float32)   # many samples leave the map
+    off.reshape(-1)[5::97] = np.nan
+    off.reshape(-1)[11::131] = np.inf
+    msk = rng.random((N, Ho, Wo, G * k * k)).astype(np.float32)
+    go = rng.standard_normal((N, Ho, Wo, G * C)).astype(np.float32)
+    tt = lambda a: torch.from_numpy(a).to(DEV)
+    gi, gof, gm = A.dcnv3_backward(tt(inp), tt(off), tt(msk), k, k, s, s, p, p, d, d, G, C, scale, tt(go))
+    gi2, gof2, gm2 = A.dcnv3_backward(tt(inp), tt(off), tt(msk), k, k, s, s, p, p, d, d, G, C, scale, tt(go))
+    ri, ro, rm = O.backward(inp, off, msk, go, k, k, s, s, p, p, d, d, G, C, scale)
+    # magnitude of the terms that enter an element of grad_input: the same scatter with absolute values
+    mi, _, _ = O.backward(np.abs(inp), off, np.abs(msk), np.abs(go), k, k, s, s, p, p, d, d, G, C, scale)
+    assert torch.isfinite(gi).all() and torch.isfinite(gof).all() and torch.isfinite(gm).all()
+    assert torch.equal(gof, gof2) and torch.equal(gm, gm2)                     # fixed reduction trees
+    assert (np.abs(gi.cpu().numpy() - ri) <= 2.0 ** -18 * mi + 1e-7).all()
+    assert (np.abs(gi2.cpu().numpy() - gi.cpu().numpy()) <= 2.0 ** -18 * mi + 1e-7).all()
+    sc_o, sc_m = np.abs(ro).max() + 1e-12, np.abs(rm).max() + 1e-12
+    np.testing.assert_allclose(gof.cpu().numpy(), ro, rtol=2e-4, atol=3e-6 * sc_o)
+    np.testing.assert_allclose(gm.cpu().numpy(), rm, rtol=2e-4, atol=3e-6 * sc_m)
+
+
+def test_backward_argument_checks():
+    x = torch.zeros(1, 4, 4, 8, device=DEV)
+    off = torch.zeros(1, 4, 4, 2 * 9 * 2, device=DEV)
+    msk = torch.zeros(1, 4, 4, 2 * 9, device=DEV)
+    go = torch.zeros(1, 4, 4, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="Not implement on cpu"):
+        A.dcnv3_backward(x.cpu(), off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 2, 4, 1.0, go)
+    with pytest.raises(RuntimeError, match="wont match"):
+        A.dcnv3_backward(x, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 3, 4, 1.0, go)
+    with pytest.raises(RuntimeError, match="geometry"):
+        A.dcnv3_backward(x, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 2, 4, 1.0, go[:, :3].contiguous())
+    gi, gof, gm = A.dcnv3_backward(x, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 2, 4, 1.0, go)
+    assert gi.shape == x.shape and gof.shape == off.shape and gm.shape == msk.shape and float(gi.abs().max()) == 0.0

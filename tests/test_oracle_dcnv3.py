@@ -42,3 +42,26 @@ def test_reference_known_answer_values():
     g = load_golden("dcnv3_kat_seed3.npz")
     np.testing.assert_allclose(g["out_f64"][0, 0, 0, :3],
                                [0.0003553824683531446, 0.0004284441152049652, 0.00037868138803360803], rtol=1e-12)
+
+
+BWD_CASES = CASES + ["dcnv3_bwd_c1.npz", "dcnv3_bwd_c30.npz", "dcnv3_bwd_c71.npz"]
+
+
+@pytest.mark.parametrize("name", BWD_CASES)
+def test_c_oracle_backward_matches_reference_autograd(name):
+    """Round 4: the C restatement of dcnv3_col2im (dcnv3_im2col_cuda.cuh:86-146, 279-857) against gradients made by autograd through the
+    reference's dcnv3_core_pytorch (gen_golden.py::gen_dcnv3; the reference's own backward test, ops_dcnv3/test.py:94-235, compares the
+    same two with rtol 1e-2 / atol 1e-3 -- the fp64 restatement is held to 1e-5 relative: the twin builds its reference points in fp32)."""
+    g = load_golden(name)
+    a = _args(g)
+    d = lambda k: g[k].astype(np.float64)
+    gi, go, gm = D.backward(d("input"), d("offset"), d("mask"), d("grad_out"), *a)
+    for ours, key in ((gi, "grad_input_f64"), (go, "grad_offset_f64"), (gm, "grad_mask_f64")):
+        ref = g[key]
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(ours, ref, rtol=1e-5, atol=2e-6 * max(scale, 1e-30) + 1e-12, err_msg=key)   # (fp32 reference points in the twin: ~1e-7 * 8 px of location error)
+    f = lambda k: g[k].astype(np.float32)
+    gi, go, gm = D.backward(f("input"), f("offset"), f("mask"), f("grad_out"), *a)
+    for ours, key in ((gi, "grad_input_f64"), (go, "grad_offset_f64"), (gm, "grad_mask_f64")):
+        np.testing.assert_allclose(ours, g[key], rtol=1e-2, atol=1e-3, err_msg=key)          # the reference's float thresholds (test.py:203-235)
+        np.testing.assert_allclose(ours, g[key], rtol=2e-3, atol=2e-5 * np.abs(g[key]).max(), err_msg=key)

@@ -3,8 +3,8 @@
 SURVEY.md section 8 row f3.  Same names, argument order and error behaviour as
 
 * ``DCNv3.dcnv3_forward``  -- the pybind module of visionllmv2/model/ops_dcnv3/src/vision.cpp (signature src/dcnv3.h:20-39);
-* ``DCNv3Function``        -- visionllmv2/model/ops_dcnv3/functions/dcnv3_func.py:21-59 (forward; the backward of the
-  reference, dcnv3_col2im, is not part of this row and raises);
+* ``DCNv3Function``        -- visionllmv2/model/ops_dcnv3/functions/dcnv3_func.py:21-59 (forward and, since round 4, backward:
+  ``dcnv3_backward`` -> ``vllm_dcnv3_backward_f32 / _f64``);
 * ``DCNv3`` (module)       -- visionllmv2/model/ops_dcnv3/modules/dcnv3.py:222-349: the projections, depth-wise conv,
   norm / activation and softmax stay torch modules with the reference's parameter names, the sampling core is the native
   kernel (fp32, as the reference upcasts around it, :330-340).
@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import _lib
@@ -57,20 +58,64 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
     return out
 
 
+def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                   group, group_channels, offset_scale, grad_output, im2col_step=256):
+    """DCNv3.dcnv3_backward (ops_dcnv3/src/dcnv3.h:41-64; functions/dcnv3_func.py:51-59): -> (grad_input, grad_offset, grad_mask),
+    shaped like input / offset / mask.  Same checks as the forward; ``im2col_step`` is validated and otherwise unused."""
+    for name, t in (("input", input), ("offset", offset), ("mask", mask), ("grad_output", grad_output)):
+        if not t.is_cuda:
+            raise RuntimeError("Not implement on cpu ({} must be a CUDA tensor)".format(name))
+        if not t.is_contiguous():
+            raise RuntimeError("{} tensor has to be contiguous".format(name))
+    if input.dtype not in (torch.float32, torch.float64) or any(t.dtype != input.dtype for t in (offset, mask, grad_output)):
+        raise RuntimeError("dcnv3_backward: input, offset, mask and grad_output must share dtype float32 or float64")
+    N, H, W, C = input.shape
+    if C != group * group_channels:
+        raise RuntimeError("Input channels and group times group channels wont match: ({} vs {}).".format(
+            C, group * group_channels))
+    step = min(N, im2col_step)
+    if N > 0 and N % step != 0:
+        raise RuntimeError("batch({}) must divide im2col_step({})".format(N, step))
+    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
+    Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    P = kernel_h * kernel_w
+    if tuple(offset.shape) != (N, Ho, Wo, group * P * 2) or tuple(mask.shape) != (N, Ho, Wo, group * P) or \
+            tuple(grad_output.shape) != (N, Ho, Wo, C):
+        raise RuntimeError("dcnv3_backward: offset / mask / grad_output do not match the output geometry [{}, {}, {}, .]".format(N, Ho, Wo))
+    grad_input = torch.zeros_like(input)      # (the sums arrive by atomics: dcnv3_cuda.cu:118 zero-fills it as well)
+    grad_offset = torch.empty_like(offset)
+    grad_mask = torch.empty_like(mask)
+    L = _lib.lib()
+    fn = L.vllm_dcnv3_backward_f32 if input.dtype == torch.float32 else L.vllm_dcnv3_backward_f64
+    with torch.cuda.device(input.device):
+        _lib.check(fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output), N, H, W, group, group_channels,
+                      kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, float(offset_scale),
+                      _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.current_stream(input.device)),
+                   "vllm_dcnv3_backward")
+    return grad_input, grad_offset, grad_mask
+
+
 class DCNv3Function(Function):
-    """functions/dcnv3_func.py:21-59 (forward)."""
+    """functions/dcnv3_func.py:21-59 (forward :23-49, backward :51-59)."""
 
     @staticmethod
     def forward(ctx, input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                 group, group_channels, offset_scale, im2col_step):
-        return dcnv3_forward(input.contiguous(), offset.contiguous(), mask.contiguous(), kernel_h, kernel_w, stride_h,
-                             stride_w, pad_h, pad_w, dilation_h, dilation_w, group, group_channels, offset_scale,
-                             im2col_step)
+        ctx.geo = (kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, group_channels,
+                   offset_scale, im2col_step)
+        input, offset, mask = input.contiguous(), offset.contiguous(), mask.contiguous()
+        ctx.save_for_backward(input, offset, mask)
+        return dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                             group, group_channels, offset_scale, im2col_step)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
-        raise NotImplementedError("DCNv3 backward (dcnv3_col2im) is not part of this build: the InternImage backbone is "
-                                  "served for inference")
+        input, offset, mask = ctx.saved_tensors
+        kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale, im2col_step = ctx.geo
+        grad_input, grad_offset, grad_mask = dcnv3_backward(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group,
+                                                            group_channels, offset_scale, grad_output.contiguous(), im2col_step)
+        return (grad_input, grad_offset, grad_mask) + (None,) * 12
 
 
 class to_channels_first(nn.Module):
