@@ -46,6 +46,21 @@ static inline bool first_use_on_device(unsigned long long *mask)
     const unsigned long long old = __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
     return !(old & bit);
 }
+// Compute units of the CURRENT device, cached per device (a `static int cus` filled from the first device queried is
+// wrong for a second, smaller device; the persistent kernels size their grids with it).
+static inline int device_cus()
+{
+    static int cache[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    int v = __atomic_load_n(&cache[d & 63], __ATOMIC_RELAXED);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        __atomic_store_n(&cache[d & 63], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

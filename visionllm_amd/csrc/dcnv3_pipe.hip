@@ -484,13 +484,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
 template <int CPG, int WIN, bool PROF>
 int dp_go(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out, hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     constexpr size_t lds = 256 + 2 * (size_t)(WIN + 64 / (CPG / 4)) * CPG * 4 + 64;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static unsigned long long attr_mask = 0;

@@ -297,13 +297,7 @@ __global__ __launch_bounds__(DT_THREADS, (2 * DT_WAVES + 3) / 4) void dcnv3_fwd_
 template <int CPG, int WIN, bool PROF>
 int dt_go(const float *in, const float *off, const float *msk, const Dcnv3Geo &q, float offset_scale, float *out, hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     constexpr size_t lds = 256 + (size_t)(WIN + 64 / (CPG / 4)) * CPG * 4 + (size_t)DT_NPX * DT_KMAX * 24 + 32;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static unsigned long long attr_mask = 0;

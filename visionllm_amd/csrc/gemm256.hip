@@ -117,7 +117,10 @@ __global__ __launch_bounds__(G2_THREADS, 1) void gemm256_bf16_kernel(const GemmA
             seg_t0 = blockIdx.x;
         } else {
             const int sb = blockIdx.x - a0_.sk_dp;
-            rid = (sb & 7) * (a0_.sk_blocks >> 3) + (sb >> 3);     // neighbours in the list sit on the same XCD (same L2)
+            // rid = block index: a finishing block only ever waits for segments of LOWER block indices, which the dispatcher starts
+            // first -- forward progress then never needs all stream-K blocks to be resident at once (the round-3 order,
+            // list neighbours on one XCD, let block 1 wait for block 248; under CU masking or a busy device that can deadlock).
+            rid = sb;
             const long total = (long)a0_.sk_tiles * nk_all;
             const int it0 = (int)(rid * total / a0_.sk_blocks), it1 = (int)((rid + 1) * total / a0_.sk_blocks);
             if (it1 <= it0) return;
@@ -773,13 +776,7 @@ static long sk_max_tiles(int cus)
 
 int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     a.nt = ceil_div(a.N, G2_BN);
     if (a.ln_in || a.ln_out) {   // folded norm: the row-wise LDS epilogue is where it lives
         VLLM_REQUIRE(epi != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && aligned16(a.Y) && a.variant256 != 5,

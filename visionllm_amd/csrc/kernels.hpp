@@ -92,6 +92,8 @@ inline void prof_mark(int tag, hipStream_t st) { if (g_prof_on) prof_mark_slow(t
 
 // Scratch of the 8-phase GEMM's stream-K tail: [4 KiB of flags, zero before the first use][SK_MAX_BLOCKS slots of 256 KiB].
 // The orchestrators reserve it in their workspace (and zero the flags once per forward); vllm_gemm_bf16_sk takes it from the caller.
+// One slot per stream-K block = per compute unit of the device the launch runs on; a device with more than SK_MAX_BLOCKS CUs (or a
+// caller's smaller buffer) simply does not get the stream-K route: gemm256_launch checks sk_ws_bytes >= cus * slot before planning it.
 constexpr long SK_FLAG_BYTES = 4096, SK_SLOT_BYTES = 32L * 512 * 16, SK_MAX_BLOCKS = 320;
 constexpr long SK_SCRATCH_BYTES = SK_FLAG_BYTES + SK_MAX_BLOCKS * SK_SLOT_BYTES;
 inline void gemm_set_scratch(GemmArgs &a, void *scratch, long bytes)

@@ -408,18 +408,7 @@ static int check_dims(int B, int S, int M, int D, int L, int Lq, int P)
     return VLLM_OK;
 }
 
-static int cu_count()
-{
-    static int n = 0;
-    if (n == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int cu_count() { return device_cus(); }
 
 template <bool BF16, int LPG>
 static int launch_vec(const void *value, const int64_t *shapes, const int64_t *lsi, const float *loc,

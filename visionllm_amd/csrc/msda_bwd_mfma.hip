@@ -415,13 +415,7 @@ int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_
                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
                          hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

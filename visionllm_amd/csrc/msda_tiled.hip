@@ -369,13 +369,7 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 1, st);
     }
     if (mode != 3 && fits32) return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, st);
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     return tiled_launch_cfg<MTCfg<8, 16, 560, 2>>(cus, value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, st);
 }
 

@@ -436,13 +436,7 @@ int msda_tiled4_launch(const float *value, const int64_t *shapes, const int64_t 
                        const float *attw, int B, int S, int M, int L, int Lq, float *out, int skip_pyramid,
                        hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tiled4_kernel<false, 4>),

@@ -499,13 +499,7 @@ int t6_go(int cus, const VT *value, const int64_t *shapes, const int64_t *lsi, c
 
 int t6_cus()
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     return cus;
 }
 

@@ -510,13 +510,7 @@ template <int WIN, bool PROF, bool EXACT>
 int t8_go(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B, int S,
           int M, int L, int Lq, float *out, uint16_t *out16, int hinted, hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     constexpr size_t lds = (size_t)(T6_ZPX + WIN + T6_SLACK) * 128 + 256;
     static_assert(lds <= 163840, "LDS budget");
     static unsigned long long attr_mask = 0;
