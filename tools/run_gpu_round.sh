@@ -1,16 +1,18 @@
-# One GPU-box pass that regenerates what profiles/r03_* quote at the end of round 3: full -m gpu suite, smoke, the default bench
+# One GPU-box pass that regenerates what profiles/r04_* quote at the end of round 4: full -m gpu suite, smoke, the default bench
 # line (ViT-L + the internvit6b key), rocprofv3 kernel stats of both workloads (csv), FETCH_SIZE / WRITE_SIZE PMC passes (separate
 # runs, kernel-trace only), the MSDA backward phase clocks.  The individual passes of the round, as they were run, are in
 # tools/gpu_passes/ (round 2's version of this script: git history).
-#   gpurun --timeout 2700 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r03z/* into profiles/ under their r03_ names
+#   gpurun --timeout 2700 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r04z/* into profiles/ under their r04_ names
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 export TMPDIR=/tmp
 make -C visionllm_amd/csrc -j16 2>&1 | tail -1   # (a stale .so once produced a wrong figure: rebuild whatever is out of date)
-O=gpurun_out/r03z
+O=gpurun_out/r04z
 mkdir -p $O
+rm -f gpurun_out/parity_contract.jsonl gpurun_out/ulp_table.jsonl
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt
+cp gpurun_out/parity_contract.jsonl $O/parity_contract.jsonl 2>/dev/null; cp gpurun_out/ulp_table.jsonl $O/ulp_table.jsonl 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1 | tee $O/smoke.txt
 timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_err.txt; tail -c 300 $O/bench_line.json
 rm -rf $O/prof_v $O/prof_i $O/fetch $O/write
@@ -26,3 +28,8 @@ python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -3
 find $O/fetch $O/write -name '*.csv' -size +2M -delete
 python tools/msda_bwd_phases.py libmsdabwd_mfma_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_mfma_phases.txt
 python tools/msda_bwd_phases.py libmsdabwd_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_lds_phases.txt
+# InternViT-6B traffic after the banded tile order (fc1 traffic <= 3x algorithmic)
+(cd /tmp; timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/fetch_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
+python tools/collect_pmc.py $O/fetch_i $O/write_i $O/pmc_traffic_internvit6b.json internvit6b | head -30
+find $O/fetch_i $O/write_i -name '*.csv' -size +2M -delete
