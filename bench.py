@@ -298,8 +298,9 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
             call, ab = layer
             call(); torch.cuda.synchronize()
             sec = event_time(call, 5)
-            out["msda_layer"] = entry("msda_layer", "vllm_msda_layer_forward (bf16 MSDeformAttn module, encoder shape Lq=S=37485, B=8: value GEMM fp32 -> query GEMM with "
-                                      "softmax + location epilogue -> msda_fwd_tiled8_kernel writing bf16 -> output GEMM)", "hbm", ab, sec, 1, HBM_PEAK_GBS,
+            out["msda_layer"] = entry("msda_layer", "vllm_msda_layer_forward (bf16 MSDeformAttn module, encoder shape Lq=S=37485, B=8: gemm_skinny_kernel value GEMM "
+                                      "fp32 -> gemm_skinny_kernel query GEMM with softmax + location epilogue -> msda_fwd_tiled8_kernel writing bf16 -> "
+                                      "gemm_skinny_kernel output GEMM)", "hbm", ab, sec, 1, HBM_PEAK_GBS,
                                       "GB/s", 1e9, algorithmic_bytes=ab,
                                       note="the layer every det-head call site runs around the operator; ONE call per instrumented step, behind the 12 "
                                            "operator calls; NOT part of the timed step / headline")

@@ -61,6 +61,11 @@ int vllm_device_info(char *name, int cap);
  * epilogue does the softmax and the location arithmetic, and takes the operator's result in bf16 straight from the
  * LDS-tiled kernel (needs L * P == 16, P even; other layers compose automatically); 0 the explicit composition (two GEMMs,
  * prep kernel, fp32 operator, conversion pass) -- the A/B reference, same results to fp32 rounding.
+ * "gemm_tile_rb" (round 4; VLLM_GEMM_TILE_RB): tile order of the persistent 8-phase GEMM: -1 automatic (default: bands of 4 row
+ * panels when the weight has >= 32 column tiles, 8 when >= 8, else the dense order), 0 dense, RB > 0 bands of RB row panels per
+ * XCD rectangle; every order gives the same bits.  "gemm_skinny" (round 4; VLLM_GEMM_SKINNY): 1 (default) K = 256, N = 256 / 256 + 128
+ * GEMMs with >= 4096 rows (the linears of a d_model = 256 deformable-attention layer) run on the weight-stationary streaming kernel
+ * (gemm_skinny.hip); 0 on the 128 x 128 tile kernel -- the same bits either way.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */

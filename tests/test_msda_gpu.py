@@ -781,6 +781,71 @@ def test_fused_layer_sampling_epilogue_matches_composition(shapes, Lq, ref_dim, 
     assert np.sqrt(((o - truth) ** 2).mean()) / rms <= max(np.sqrt(((ref_bf16 - truth) ** 2).mean()) / rms * 1.05, 4e-3)
 
 
+@pytest.mark.parametrize("B,shapes,Lq,ref_dim,four_d,masked", [
+    (2, [(60, 64), (30, 32), (15, 16), (8, 8)], None, 2, 0, True),     # encoder shape: M = 2 * 5104 rows (M % 4 == 0: the mask travels with the chunks)
+    (3, [(60, 64), (30, 32), (15, 16), (8, 8)], 1371, 4, 0, True),     # boxes; query rows 4113 = 64 * 64 + 17 (ragged last chunk)
+    (3, [(60, 64), (30, 32), (15, 16), (8, 8)], 1371, 4, 1, False),    # UniPose 4D normalizer, no mask
+    (1, [(61, 67), (30, 32), (15, 16), (8, 8)], None, 2, 0, True),     # M = 5367 (M % 4 != 0): the masked value GEMM stays on the tile kernel
+])
+def test_skinny_gemm_layer_bit_identical_to_tile_kernel(B, shapes, Lq, ref_dim, four_d, masked):
+    """The weight-stationary streaming GEMM (gemm_skinny.hip: K = 256, N = 256 / 384, >= 4096 rows) against the 128 x 128 tile kernel
+    it replaces for the layer's three linears -- same MFMA, same K order, same epilogue arithmetic -> the layer's output is the
+    same bits with the option on and off (value GEMM with / without key-padding mask, query GEMM with the softmax / location
+    epilogue for 2-d / 4-d reference points, output GEMM), and two runs agree (race screen of the 4-stage ring)."""
+    from visionllm_amd import _lib
+    mod, q, ref, src, ss, lsi, mask = _layer_case(B, shapes, Lq, ref_dim, four_d, seed=77 + ref_dim + four_d, masked=masked)
+    with torch.no_grad():
+        old = _lib.lib().vllm_set_option(b"gemm_skinny", 0)
+        try:
+            tile = mod(q, ref, src, ss, lsi, mask)
+            _lib.lib().vllm_set_option(b"gemm_skinny", 1)
+            skinny = mod(q, ref, src, ss, lsi, mask)
+            again = mod(q, ref, src, ss, lsi, mask)
+        finally:
+            _lib.lib().vllm_set_option(b"gemm_skinny", old)
+    assert torch.isfinite(skinny.float()).all()
+    assert torch.equal(skinny, again)
+    assert torch.equal(skinny, tile), float((skinny.float() - tile.float()).abs().max())
+
+
+@pytest.mark.parametrize("M", [4096, 4097, 5000, 16384 + 63, 70001])
+@pytest.mark.parametrize("epi", ["bias", "f32", "f32_masked"])
+def test_skinny_gemm_vs_tile_kernel_and_fp32(M, epi):
+    """The same through the C entry point `vllm_gemm_bf16` (K = 256, N = 256): automatic choice (the streaming kernel) against
+    VLLM_GEMM_FORCE_128, bit for bit, ragged row counts (last chunk of 1 ... 63 rows, more chunks than CUs and fewer), strided
+    input rows; and against torch fp32 within the GEMM's per-element bound."""
+    from visionllm_amd import _lib
+    torch.manual_seed(M)
+    K = N = 256
+    ldx = 256 if M % 2 else 320
+    xs = _bf(torch.randn(M, ldx, device=DEV))
+    x = xs[:, :K]
+    w = _bf(torch.randn(N, K, device=DEV) * 0.06)
+    b = _bf(torch.randn(N, device=DEV))
+    masked = epi == "f32_masked"
+    if masked and M % 4:
+        pytest.skip("a mask with M % 4 != 0 stays on the tile kernel (covered by the layer test)")
+    mask = (torch.rand(M, device=DEV) < 0.2).to(torch.uint8) if masked else None
+    f32 = epi != "bias"
+    code = 5 if f32 else 0
+
+    def run(force):
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        _lib.check(_lib.lib().vllm_gemm_bf16(_lib.ptr(xs), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, N, K, ldx, K, N, code | force, None,
+                                             _lib.ptr(mask) if masked else None, 0, 0, _lib.current_stream()), "gemm")
+        return y
+    auto, auto2, tile = run(0), run(0), run(0x100)
+    assert torch.equal(auto, auto2)
+    assert torch.equal(auto, tile), float((auto.float() - tile.float()).abs().max())
+    ref = x.float() @ w.float().t() + b.float()
+    if masked:
+        ref = ref.masked_fill(mask.bool()[:, None], 0.0)
+    mag = x.float().abs() @ w.float().abs().t() + b.float().abs()
+    err = (auto.float() - ref).abs()
+    bound = mag * 2.0 ** -17 + (ref.abs() * 2.0 ** -8 if not f32 else 0.0) + 1e-6
+    assert bool((err <= bound).all()), float((err / bound).max())
+
+
 def test_fused_layer_module_flavours_and_fallbacks():
     shapes = [(12, 16), (6, 8), (3, 4)]
     mod, q, ref, src, ss, lsi, mask = _layer_case(2, shapes, 40, 2, 0, seed=5, C=128, M=4)

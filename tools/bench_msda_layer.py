@@ -63,6 +63,9 @@ def main():
                 print(json.dumps(dict(case=name, structure=args.only, us=timeit(lambda: mod(q, ref, src, ss, lsi, None)) * 1e6)))
                 continue
             fused = timeit(lambda: mod(q, ref, src, ss, lsi, None))
+            _lib.lib().vllm_set_option(b"gemm_skinny", 0)        # round 3: the three linears on the 128 x 128 tile kernel
+            fused_tile = timeit(lambda: mod(q, ref, src, ss, lsi, None))
+            _lib.lib().vllm_set_option(b"gemm_skinny", 1)
             _lib.lib().vllm_set_option(b"msda_layer_fused", 0)   # round-1 launch structure: 2 query GEMMs + prep + cvt
             fused_r1 = timeit(lambda: mod(q, ref, src, ss, lsi, None))
             _lib.lib().vllm_set_option(b"msda_layer_fused", 1)
@@ -73,7 +76,7 @@ def main():
             finally:
                 A.msda_layer_fused_ok = ok
         flops = 2.0 * B * C * (S * C + Lq * (M * L * P * 3) + Lq * C)
-        print(json.dumps(dict(case=name, B=B, Lq=Lq, fused_us=fused * 1e6, fused_round1_structure_us=fused_r1 * 1e6, composed_us=composed * 1e6,
+        print(json.dumps(dict(case=name, B=B, Lq=Lq, fused_us=fused * 1e6, fused_with_tile_kernel_gemms_us=fused_tile * 1e6, fused_round1_structure_us=fused_r1 * 1e6, composed_us=composed * 1e6,
                               speedup=composed / fused, gemm_gflop=flops / 1e9)))
 
 

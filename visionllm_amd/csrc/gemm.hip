@@ -266,8 +266,11 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                          aligned16(a.W2) && aligned16(a.Y2) && aligned16(a.Y) && (a.ref_dim == 2 || a.ref_dim == 4) &&
                          (reinterpret_cast<uintptr_t>(a.ref) & (a.ref_dim == 4 ? 15u : 7u)) == 0,
                      "gemm: bad operands for the MSDA sampling epilogue");
-        a.variant = 1;
     }
+    // tall, skinny K = 256 problems (the linears of a deformable-attention layer): weight-stationary streaming kernel, bit-identical
+    // to the 128 x 128 kernel below.  A forced variant (tests / tuning) keeps its kernel.
+    if (a.variant == 0 && gemm_skinny_takes(epi, a)) return gemm_skinny_launch(epi, a, st);
+    if (epi == EPI_MSDA) a.variant = 1;
     if (a.variant == 4) { a.variant = 2; a.variant256 = 5; }   // 8-phase schedule on the 32x32x16 instruction
     VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");
     if (a.ln_in || a.ln_out) {   // folded norm: only the 8-phase kernel implements it

@@ -75,6 +75,11 @@ extern int g_gemm_tile_rb;
 int gemm_tile_rb();            // VLLM_GEMM_TILE_RB / vllm_set_option("gemm_tile_rb"): -1 automatic, 0 dense XCD order, RB > 0 banded
 int attn_variant();            // VLLM_ATTN_VARIANT / vllm_set_option("attn_variant"): bit0 pipe, bit1 defer, bit2 prio,
                                // bit3 asm tr-reads, bit4 no padding trim, 32 = automatic (default)
+// gemm_skinny.hip: K = 256, N = 256 / 384 (the linears of a deformable-attention layer); VLLM_GEMM_SKINNY / option "gemm_skinny"
+bool gemm_skinny_takes(int epi, const GemmArgs &a);
+int gemm_skinny_launch(int epi, const GemmArgs &a, hipStream_t st);
+int gemm_skinny_enabled();
+int gemm_skinny_set(int v);
 int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 

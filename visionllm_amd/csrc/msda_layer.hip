@@ -250,7 +250,7 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
         GemmArgs a;
         a.X = query; a.W = d->sampling_offsets_w; a.Y = (uint16_t *)off; a.bias = d->sampling_offsets_b; a.scale = nullptr;
         a.res = nullptr; a.M = B * Lq; a.N = MLP * 3; a.K = C; a.ldx = C; a.ldw = C; a.ldy = MLP * 2; a.ldr = 0; a.P = 0;
-        a.mt = a.nt = 0; a.xP = 0; a.variant = 1; a.variant256 = 0; a.direct_store = 0;
+        a.mt = a.nt = 0; a.xP = 0; a.variant = 0; a.variant256 = 0; a.direct_store = 0;
         a.W2 = d->attention_weights_w; a.bias2 = d->attention_weights_b; a.Y2 = lg; a.ldy2 = MLP; a.nsplit = MLP * 2;
         a.ref = ref; a.shapes = shapes; a.mL = L; a.mP = P; a.ref_dim = d->ref_dim; a.four_d = d->use_4d_normalizer;
         TRY(gemm_bf16_launch(EPI_MSDA, a, st));
