@@ -808,6 +808,40 @@ def test_skinny_gemm_layer_bit_identical_to_tile_kernel(B, shapes, Lq, ref_dim, 
     assert torch.equal(skinny, tile), float((skinny.float() - tile.float()).abs().max())
 
 
+@pytest.mark.parametrize("B,shapes,ref_dim,four_d", [
+    (1, [(64, 72), (32, 36), (16, 18)], 2, 0),     # the 3-level pixel decoder (msdeformattn_pixel_decoder.py:57-58): L * P = 12
+    (2, [(48, 40), (24, 20), (12, 10)], 4, 1),     # 3 levels, boxes, 4D normaliser
+    (1, [(64, 80), (32, 40)], 2, 0),               # 2 levels: L * P = 8
+    (1, [(72, 64)], 4, 0),                         # 1 level
+])
+def test_fused_layer_fewer_than_four_levels_streaming_epilogue(B, shapes, ref_dim, four_d):
+    """L * P in {4, 8, 12}: with d_model 256, 8 heads, 4 points and >= 4096 query rows the query GEMM's
+    softmax / location epilogue runs in the streaming kernel (a head's 8 L offsets / 4 L logits padded to 32 / 16 feature slots of
+    its wave) -- against the explicit composition (two GEMMs + msda_prep_generic_kernel, which sums the L * P exponentials
+    sequentially: same value to fp32 rounding, not the same bits) and against the fp64 oracle."""
+    from visionllm_amd import _lib
+    mod, q, ref, src, ss, lsi, mask = _layer_case(B, shapes, None, ref_dim, four_d, seed=31 + len(shapes) + ref_dim)
+    assert q.shape[0] * q.shape[1] >= 4096
+    with torch.no_grad():
+        old = _lib.lib().vllm_set_option(b"msda_layer_fused", 0)
+        try:
+            composed = mod(q, ref, src, ss, lsi, mask)
+            _lib.lib().vllm_set_option(b"msda_layer_fused", 1)
+            fused = mod(q, ref, src, ss, lsi, mask)
+            again = mod(q, ref, src, ss, lsi, mask)
+        finally:
+            _lib.lib().vllm_set_option(b"msda_layer_fused", old)
+    assert torch.isfinite(fused.float()).all() and torch.equal(fused, again)
+    d = (fused.float() - composed.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(composed.float().abs().max()), float(d.max())     # at most an output ulp or two
+    assert float((d > 0).float().mean()) < 0.02                                                    # ... and rarely
+    truth, ref_bf16 = _layer_truth(mod, q, ref, src, ss, lsi, mask)
+    o = fused.double().cpu().numpy()
+    rms = np.sqrt((truth ** 2).mean())
+    assert np.sqrt(((o - truth) ** 2).mean()) / rms <= max(np.sqrt(((ref_bf16 - truth) ** 2).mean()) / rms * 1.05, 4e-3)
+    assert np.abs(o - truth).max() <= 2e-2 * np.abs(truth).max()
+
+
 @pytest.mark.parametrize("M", [4096, 4097, 5000, 16384 + 63, 70001])
 @pytest.mark.parametrize("epi", ["bias", "f32", "f32_masked"])
 def test_skinny_gemm_vs_tile_kernel_and_fp32(M, epi):

@@ -260,6 +260,10 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                  "gemm: operands must be 16-byte aligned with row strides multiple of 8 elements");
     VLLM_REQUIRE(epi != EPI_RESIDUAL || (a.res && a.ldr % 4 == 0), "gemm: residual epilogue needs res");
     VLLM_REQUIRE(epi != EPI_EMBED || (a.res && a.P > 0), "gemm: embed epilogue needs the position table and P");
+    // tall, skinny K = 256 problems (the linears of a deformable-attention layer): weight-stationary streaming kernel, bit-identical
+    // to the 128 x 128 kernel below where both serve the shape (its EPI_MSDA form also takes L = 1 ... 3 levels, which the tile
+    // kernel's epilogue does not).  A forced variant (tests / tuning) keeps its kernel.
+    if (a.variant == 0 && gemm_skinny_takes(epi, a)) return gemm_skinny_launch(epi, a, st);
     if (epi == EPI_MSDA) {
         VLLM_REQUIRE(a.W2 && a.Y2 && a.ref && a.shapes && a.mL > 0 && a.mP > 0 && a.mP % 2 == 0 && a.mL * a.mP == 16 &&
                          a.nsplit % BN == 0 && a.nsplit > 0 && a.nsplit < a.N && (a.N - a.nsplit) % 16 == 0 && a.ldy2 % 4 == 0 &&
@@ -267,9 +271,6 @@ int gemm_bf16_launch(int epi, GemmArgs a, hipStream_t st)
                          (reinterpret_cast<uintptr_t>(a.ref) & (a.ref_dim == 4 ? 15u : 7u)) == 0,
                      "gemm: bad operands for the MSDA sampling epilogue");
     }
-    // tall, skinny K = 256 problems (the linears of a deformable-attention layer): weight-stationary streaming kernel, bit-identical
-    // to the 128 x 128 kernel below.  A forced variant (tests / tuning) keeps its kernel.
-    if (a.variant == 0 && gemm_skinny_takes(epi, a)) return gemm_skinny_launch(epi, a, st);
     if (epi == EPI_MSDA) a.variant = 1;
     if (a.variant == 4) { a.variant = 2; a.variant256 = 5; }   // 8-phase schedule on the 32x32x16 instruction
     VLLM_REQUIRE(a.variant != 3, "gemm: the 4-wave 128x128-per-wave variant lives in tools/experiments (not built)");

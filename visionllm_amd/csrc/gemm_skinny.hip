@@ -87,38 +87,54 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
     const int nchunks = (a.M + SK_R - 1) / SK_R;
     const int n_it = (nchunks - (int)blockIdx.x + G - 1) / G;   // >= 1: the launcher never starts more blocks than chunks
 
-    // ---- the wave's feature tiles (16 features each).  EPI_MSDA: wave w = head w -- its 32 offsets (two tiles of W) and its 16
-    // logits (one tile of W2); otherwise NWC consecutive tiles ----
+    // ---- the wave's feature tiles (16 features each): NWC consecutive tiles.  EPI_MSDA: wave w = head w, for L <= 4 levels of P = 4
+    // points: its 8 L offsets in two tiles of W (slots beyond 8 L are padding: computed from a repeated weight row, never
+    // stored) and its 4 L logits in one tile of W2 (padding slots take no part in the softmax) ----
+    const int mL = EPI == EPI_MSDA ? a.mL : 4, OFFH = 8 * mL, LGH = 4 * mL;
     int nt[NWC];
 #pragma unroll
-    for (int i = 0; i < NWC; ++i) nt[i] = EPI == EPI_MSDA ? (i < 2 ? wave * 32 + i * 16 : a.nsplit + wave * 16) : (wave * NWC + i) * 16;
+    for (int i = 0; i < NWC; ++i) nt[i] = (wave * NWC + i) * 16;
     bf16x8_t wf[NWC][SK_KS];
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const uint16_t *src = (EPI == EPI_MSDA && i == 2) ? a.W2 + (size_t)(nt[i] - a.nsplit + fr) * a.ldw : a.W + (size_t)(nt[i] + fr) * a.ldw;
+        const uint16_t *src;
+        if (EPI == EPI_MSDA) {
+            const int f = i * 16 + fr;
+            src = i < 2 ? a.W + (size_t)(wave * OFFH + (f < OFFH ? f : OFFH - 1)) * a.ldw : a.W2 + (size_t)(wave * LGH + (fr < LGH ? fr : LGH - 1)) * a.ldw;
+        } else src = a.W + (size_t)(nt[i] + fr) * a.ldw;
 #pragma unroll
         for (int ks = 0; ks < SK_KS; ++ks) wf[i][ks] = *reinterpret_cast<const bf16x8_t *>(src + ks * 32 + kq * 8);
     }
-    // per-lane epilogue constants: bias of features nt[i] + 4 kq .. + 3
+    // per-lane epilogue constants: the lane's 4 features of tile i (EPI_MSDA: slot 16 i + 4 kq of the head's offsets, 4 kq of its
+    // logits; `live`: not a padding slot), their bias
+    bool live[NWC];
+    int col[NWC];      // first of the lane's 4 output columns in Y (tiles 0 .. ) / Y2 (EPI_MSDA tile 2)
     float bia[NWC][4];
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const uint16_t *bp = (EPI == EPI_MSDA && i == 2) ? (a.bias2 ? a.bias2 - a.nsplit : nullptr) : a.bias;
+        const uint16_t *bp = a.bias;
+        live[i] = true;
+        col[i] = nt[i] + kq * 4;
+        if (EPI == EPI_MSDA) {
+            if (i < 2) { live[i] = i * 16 + kq * 4 < OFFH; col[i] = wave * OFFH + i * 16 + kq * 4; }
+            else { live[i] = kq * 4 < LGH; col[i] = wave * LGH + kq * 4; bp = a.bias2; }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) bia[i][r] = 0.f;
-        if (bp) {
-            const uint2_t b = *reinterpret_cast<const uint2_t *>(bp + nt[i] + kq * 4);
+        if (bp && live[i]) {
+            const uint2_t b = *reinterpret_cast<const uint2_t *>(bp + col[i]);
             bia[i][0] = bf16lo_to_f32(b.x); bia[i][1] = bf16hi_to_f32(b.x); bia[i][2] = bf16lo_to_f32(b.y); bia[i][3] = bf16hi_to_f32(b.y);
         }
     }
-    // EPI_MSDA: the level of this lane's two points in offset tile i is 2 i + (kq >> 1)  ((head, level, point, xy) order, P = 4
-    // points of 2 coordinates per level = 8 features); 1 / W, 1 / H of the two levels
+    // EPI_MSDA: the level of this lane's two points in offset tile i  ((head, level, point, xy) order, P = 4 points of 2 coordinates
+    // per level = 8 features: level (16 i + 4 kq) / 8); W, H of the two levels
     float lW[2] = {1.f, 1.f}, lH[2] = {1.f, 1.f};
     int lvl[2] = {0, 0};
     if (EPI == EPI_MSDA) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            lvl[i] = ((i * 16 + kq * 4) / (2 * a.mP)) % a.mL;
+            lvl[i] = (i * 16 + kq * 4) / 8;
+            lvl[i] = lvl[i] < mL ? lvl[i] : mL - 1;
             lW[i] = (float)a.shapes[2 * lvl[i] + 1];
             lH[i] = (float)a.shapes[2 * lvl[i]];
         }
@@ -133,12 +149,14 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
         const int row = (wave * 4 + s) * 2 + (lane >> 5);
         xvo[s] = ((unsigned)(lane >> 5) * (unsigned)a.ldx + (unsigned)(((lane & 31) ^ (row & 15)) * 8)) * 2u;
     }
-    // aux descriptor / per-lane offset
+    // aux descriptor / per-lane offset (EPI_MSDA: the chunk's reference points are 64 rows x L x RD floats = ROWB bytes per row,
+    // contiguous; wave w fetches KiB w of them while that starts inside the block)
+    const int ROWB = mL * RD * 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
         AUX == 1 ? (void *)a.res : (void *)a.ref, 0,
-        AUX == 1 ? a.M : AUX ? (int)((unsigned)a.M * (unsigned)a.mL * (unsigned)RD * 4u) : 0, 0x00020000);
+        AUX == 1 ? a.M : AUX ? (int)((unsigned)a.M * (unsigned)ROWB) : 0, 0x00020000);
     const unsigned avo = AUX == 1 ? (lane < 16 ? (unsigned)lane * 4u : 0x80000000u)
-                                  : (wave * 1024 < SK_R * 4 * RD * 4 ? (unsigned)(wave * 1024 + lane * 16) : 0x80000000u);   // (a.mL == 4: takes())
+                                  : (wave * 1024 < SK_R * ROWB ? (unsigned)(wave * 1024 + lane * 16) : 0x80000000u);
     auto issue_chunk = [&](int it) {   // chunk blockIdx.x + it * G into stage it % SK_S (chunks past the end: all zeros, no traffic)
         const unsigned chunk = (unsigned)((int)blockIdx.x + it * G);
         const unsigned row0 = chunk * (unsigned)SK_R + (unsigned)wave * 8u;
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                                                      (int)avo, (int)(chunk * (unsigned)SK_R), 0, 0);
         else if (AUX)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(smem + SK_S * SK_STAGE + (it % SK_S) * SK_AUX + wave * 1024), 16,
-                                                     (int)avo, (int)(chunk * (unsigned)(SK_R * 4 * RD * 4)), 0, 0);
+                                                     (int)avo, (int)(chunk * (unsigned)(SK_R * ROWB)), 0, 0);
     };
     // B fragment (rows j * 16 + fr, K step ks): physical chunk ((ks << 2) | kq) ^ fr = (ks << 2) ^ (kq ^ fr); bit 4 of it is ks >> 2
     // (plain + 256 bytes), bits 2 - 3 mix with (ks & 3): four per-lane bases, everything else is an immediate
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
     for (int q = 0; q < 4; ++q) xa4[q] = (unsigned)(fr * 512 + ((((q << 2) ^ (kq ^ fr)) & 15) << 4));
 
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a.Y, 0, (int)(((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)(EPI == EPI_MSDA ? a.nsplit : a.N)) * (EPI == EPI_BIAS ? 2u : 4u)), 0x00020000);
+        (void *)a.Y, 0, (int)(((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)(EPI == EPI_MSDA ? a.nsplit : a.N)) * (EPI == EPI_BIAS ? 2u : 4u)), 0x00020000);   // (EPI_MSDA: nsplit = 8 heads x 8 L offsets)
     const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)a.Y2, 0, EPI == EPI_MSDA ? (int)(((unsigned)(a.M - 1) * (unsigned)a.ldy2 + (unsigned)(a.N - a.nsplit)) * 4u) : 0, 0x00020000);
 
@@ -228,21 +246,23 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                          : "=&v"(dead[0]), "=&v"(dead[1]), "=&v"(dead[2]), "=&v"(dead[3]) : "v"(ad) : "memory");
         } else if constexpr (AUX == 2) {
             float2_t t2[2][4];
-            const unsigned a0 = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * 32 + lvl[0] * 8), a1 = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * 32 + lvl[1] * 8);
-            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\tds_read_b64 %2, %8 offset:1024\n\tds_read_b64 %3, %8 offset:1536\n\t"
-                         "ds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:512\n\tds_read_b64 %6, %9 offset:1024\n\tds_read_b64 %7, %9 offset:1536\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(t2[0][0]), "=&v"(t2[0][1]), "=&v"(t2[0][2]), "=&v"(t2[0][3]), "=&v"(t2[1][0]), "=&v"(t2[1][1]), "=&v"(t2[1][2]), "=&v"(t2[1][3])
-                         : "v"(a0), "v"(a1) : "memory");
+            const unsigned ab = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * ROWB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("ds_read_b64 %0, %1" : "=v"(t2[i][j]) : "v"(ab + (unsigned)(j * 16 * ROWB + lvl[i] * 8)));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t2[0][0]), "+v"(t2[0][1]), "+v"(t2[0][2]), "+v"(t2[0][3]), "+v"(t2[1][0]), "+v"(t2[1][1]), "+v"(t2[1][2]), "+v"(t2[1][3]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rp[i][j] = (float4_t){t2[i][j].x, t2[i][j].y, 0.f, 0.f};
         } else if constexpr (AUX == 3) {
-            const unsigned a0 = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * 64 + lvl[0] * 16), a1 = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * 64 + lvl[1] * 16);
-            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
-                         "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(rp[0][0]), "=&v"(rp[0][1]), "=&v"(rp[0][2]), "=&v"(rp[0][3]), "=&v"(rp[1][0]), "=&v"(rp[1][1]), "=&v"(rp[1][2]), "=&v"(rp[1][3])
-                         : "v"(a0), "v"(a1) : "memory");
+            const unsigned ab = (unsigned)(SK_S * SK_STAGE + (it % SK_S) * SK_AUX + fr * ROWB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(rp[i][j]) : "v"(ab + (unsigned)(j * 16 * ROWB + lvl[i] * 16)));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rp[0][0]), "+v"(rp[0][1]), "+v"(rp[0][2]), "+v"(rp[0][3]), "+v"(rp[1][0]), "+v"(rp[1][1]), "+v"(rp[1][2]), "+v"(rp[1][3]));
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                 const unsigned so = (unsigned)(m0 + j * 16) * (unsigned)a.ldy * 4u;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const unsigned vo = ((unsigned)fr * (unsigned)a.ldy + (unsigned)(nt[i] + kq * 4)) * 4u;
+                    const unsigned vo = live[i] ? ((unsigned)fr * (unsigned)a.ldy + (unsigned)col[i]) * 4u : 0x80000000u;
                     const float v[4] = {acc[i][j][0] + bia[i][0], acc[i][j][1] + bia[i][1], acc[i][j][2] + bia[i][2], acc[i][j][3] + bia[i][3]};
                     const float4_t r = rp[i][j];
                     float sx, sy;
@@ -297,7 +317,9 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                     sk_store16(o, yrs, vo, so);
                 }
                 {   // the head's 16 logits of row fr: 4 in this lane, the others 16 / 32 / 48 lanes away
-                    const float v[4] = {acc[2][j][0] + bia[2][0], acc[2][j][1] + bia[2][1], acc[2][j][2] + bia[2][2], acc[2][j][3] + bia[2][3]};
+                    const float ninf = -__builtin_huge_valf();
+                    const float v[4] = {live[2] ? acc[2][j][0] + bia[2][0] : ninf, live[2] ? acc[2][j][1] + bia[2][1] : ninf,
+                                        live[2] ? acc[2][j][2] + bia[2][2] : ninf, live[2] ? acc[2][j][3] + bia[2][3] : ninf};   // (padding: exp -> 0)
                     float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), p, q;
                     xchg16(mx, p, q); mx = fmaxf(p, q);
                     xchg32(mx, p, q); mx = fmaxf(p, q);
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                     const float inv = 1.f / sum;
                     const float o0 = e[0] * inv, o1 = e[1] * inv, o2 = e[2] * inv, o3 = e[3] * inv;
                     const u32x4_t o = {__builtin_bit_cast(unsigned, o0), __builtin_bit_cast(unsigned, o1), __builtin_bit_cast(unsigned, o2), __builtin_bit_cast(unsigned, o3)};
-                    const unsigned vo2 = ((unsigned)fr * (unsigned)a.ldy2 + (unsigned)(nt[2] - a.nsplit + kq * 4)) * 4u;
+                    const unsigned vo2 = live[2] ? ((unsigned)fr * (unsigned)a.ldy2 + (unsigned)col[2]) * 4u : 0x80000000u;
                     sk_store16(o, y2rs, vo2, (unsigned)(m0 + j * 16) * (unsigned)a.ldy2 * 4u);
                 }
             }
@@ -331,7 +353,8 @@ int gemm_skinny_enabled()
 }
 int gemm_skinny_set(int v) { const int old = gemm_skinny_enabled(); g_skinny = v != 0; return old; }
 
-// Does the shape belong here?  K = 256, N = 256 (fp32 / bias epilogues) or 256 + 128 with 8 heads of 4 levels x 4 points (EPI_MSDA), plain rows.
+// Does the shape belong here?  K = 256, N = 256 (fp32 / bias epilogues) or 8 heads x (8 L offsets + 4 L logits), L <= 4 levels of 4 points
+// (EPI_MSDA: 256 + 128 features at L = 4, 192 + 96 for the 3-level pixel decoder, msdeformattn_pixel_decoder.py:57-58), plain rows.
 bool gemm_skinny_takes(int epi, const GemmArgs &a)
 {
     if (!gemm_skinny_enabled() || a.K != SK_K || a.M < 4096 || a.xP != 0 || a.ln_in || a.ln_out) return false;
@@ -339,9 +362,10 @@ bool gemm_skinny_takes(int epi, const GemmArgs &a)
     if (epi == EPI_BIAS) return a.N == 256 && a.ldy >= 256;
     if (epi == EPI_F32)   // (the mask travels as dwords: M % 4 == 0 keeps the last one inside the array)
         return a.N == 256 && a.ldy >= 256 && (!a.res || (a.M % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 3u) == 0));
-    if (epi == EPI_MSDA)
-        return a.N == 384 && a.nsplit == 256 && a.mL == 4 && a.mP == 4 && a.ldy >= 256 && a.ldy2 >= 128 && aligned16(a.ref) &&
-               (long)a.M * a.ldy2 * 4 < (1L << 31);
+    if (epi == EPI_MSDA)   // 8 heads x L <= 4 levels x 4 points: N = 8 (8 L + 4 L)
+        return a.mL >= 1 && a.mL <= 4 && a.mP == 4 && a.N == 96 * a.mL && a.nsplit == 64 * a.mL && a.ldy >= a.nsplit && a.ldy % 4 == 0 &&
+               a.ldy2 >= a.N - a.nsplit && a.ldy2 % 4 == 0 && a.W2 && a.Y2 && a.ref && a.shapes && aligned16(a.ref) && aligned16(a.W2) &&
+               aligned16(a.Y2) && (a.ref_dim == 2 || a.ref_dim == 4) && (long)a.M * a.ldy2 * 4 < (1L << 31);
     return false;
 }
 

@@ -245,14 +245,19 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D]
     TRY(gemm(st, EPI_F32, input_flatten, C, d->value_proj_w, C, d->value_proj_b, (uint16_t *)value, C, B * S, C, C, nullptr,
              (const uint16_t *)padding_mask));
-    if (L * P == 16 && P % 2 == 0 && (MLP * 2) % 128 == 0 && !layer_unfused()) {
-        // offsets and logits of the queries (:110-111) in one GEMM; softmax + location arithmetic (:112-129) in its epilogue
-        GemmArgs a;
+    // offsets and logits of the queries (:110-111) in one GEMM; softmax + location arithmetic (:112-129) in its epilogue: the tile
+    // kernel's form needs L * P == 16; the streaming kernel's (gemm_skinny.hip: d_model 256, 8 heads, 4 points, >= 4096 query
+    // rows) also takes 1 ... 3 levels -- the 3-level pixel decoder (msdeformattn_pixel_decoder.py:57-58)
+    GemmArgs a;
+    {
         a.X = query; a.W = d->sampling_offsets_w; a.Y = (uint16_t *)off; a.bias = d->sampling_offsets_b; a.scale = nullptr;
         a.res = nullptr; a.M = B * Lq; a.N = MLP * 3; a.K = C; a.ldx = C; a.ldw = C; a.ldy = MLP * 2; a.ldr = 0; a.P = 0;
         a.mt = a.nt = 0; a.xP = 0; a.variant = 0; a.variant256 = 0; a.direct_store = 0;
         a.W2 = d->attention_weights_w; a.bias2 = d->attention_weights_b; a.Y2 = lg; a.ldy2 = MLP; a.nsplit = MLP * 2;
         a.ref = ref; a.shapes = shapes; a.mL = L; a.mP = P; a.ref_dim = d->ref_dim; a.four_d = d->use_4d_normalizer;
+    }
+    const bool tile_form = L * P == 16 && P % 2 == 0 && (MLP * 2) % 128 == 0;
+    if (!layer_unfused() && (tile_form || gemm_skinny_takes(EPI_MSDA, a))) {
         TRY(gemm_bf16_launch(EPI_MSDA, a, st));
     } else {
         // offsets / logits of the queries (:110-111) -- fp32 [B*Lq, M*L*P*2], [B*Lq, M*L*P]
