@@ -312,6 +312,10 @@ int vllm_layernorm_bf16(const uint16_t *x, int ldx, const uint16_t *weight, cons
  * (visionllmv2/model/internvit/flash_attention.py:30-75).  D in {64,128}. */
 int vllm_attn_fwd_qkvpacked_bf16(const uint16_t *qkv, uint16_t *out, int B, int S, int H, int D,
                                  float softmax_scale, vllm_stream_t stream);
+/* The same for IEEE-half qkv / out (round 4): the reference's module accepts both dtypes (`assert qkv.dtype in [torch.float16,
+ * torch.bfloat16]`, flash_attention.py:39-41).  fp32 scores / softmax / accumulation; P is rounded to half before P V. */
+int vllm_attn_fwd_qkvpacked_f16(const uint16_t *qkv, uint16_t *out, int B, int S, int H, int D,
+                                float softmax_scale, vllm_stream_t stream);
 
 /* Patch gather for the embedding GEMM: pixels [N,3,img,img] (bf16, or fp32 when pixel_is_f32) ->
  * A [N*(img/patch)^2, Kpad] bf16, k = c*patch^2 + ky*patch + kx, zero padded to Kpad. */

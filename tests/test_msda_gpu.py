@@ -578,6 +578,26 @@ def test_modules_match_oracle_composition():
     o2 = mm(q.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts,
             spatial_shapes=ss, level_start_index=lsi)
     torch.testing.assert_close(o2.permute(1, 0, 2), expect + q, rtol=1e-4, atol=1e-4)
+    # the fork-added class (mmcv/ops/multi_scale_deform_attn_optimized.py:160): same parameters, same forward, the operator in value's
+    # own dtype -- fp32: the same bits as the class above; fp64 runs in fp64 (the base class would compute it in fp64 too: mmcv's
+    # cast is to fp32 only for lower precisions); gradients flow through the list-returning backward
+    mo = A.MultiScaleDeformableAttentionOptimized(embed_dims=64, num_heads=4, num_levels=2, num_points=4, dropout=0.0).to(DEV)
+    mo.load_state_dict(mm.state_dict(), strict=True)
+    o2o = mo(q.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts,
+             spatial_shapes=ss, level_start_index=lsi)
+    assert torch.equal(o2o, o2)
+    qg = q.detach().clone().requires_grad_(True)
+    mo(qg.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts, spatial_shapes=ss,
+       level_start_index=lsi).square().sum().backward()
+    qh = q.detach().clone().requires_grad_(True)
+    mm(qh.permute(1, 0, 2), value=src.permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts, spatial_shapes=ss,
+       level_start_index=lsi).square().sum().backward()
+    torch.testing.assert_close(qg.grad, qh.grad, rtol=1e-4, atol=1e-5)
+    mo64 = mo.double()
+    o64 = mo64(q.double().permute(1, 0, 2), value=src.double().permute(1, 0, 2), key_padding_mask=mask, reference_points=ref_pts.double(),
+               spatial_shapes=ss, level_start_index=lsi)
+    assert o64.dtype == torch.float64
+    torch.testing.assert_close(o64.float(), o2, rtol=1e-4, atol=1e-4)
 
     class Cfg:
         d_model, num_feature_levels, disable_custom_kernels = 64, 2, False

@@ -81,7 +81,7 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
 // bit2: s_setprio(1) around the MFMA clusters; bit3: V transpose-reads issued as inline asm BEFORE the softmax (the
 // compiler treats the tr-read builtin as 'may alias the LDS-DMA in flight' and puts s_waitcnt vmcnt(0) in front of it,
 // which drains the next tile's prefetch in the middle of every iteration).
-template <int D, int VAR>
+template <int D, int VAR, bool F16 = false>
 __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void attn_fwd_kernel(const AttnArgs a)
 {
     constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0, ASMTR = (VAR & 8) != 0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf = *(const __attribute__((address_space(3))) bf16x8_t *)(uintptr_t)(ks_ + kofs[ks] + kb * 32 * (D * 2));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+                st[kb] = mfma16<F16>(kf, qf[ks], st[kb]);
             }
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -209,8 +209,6 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         }
         // Row sums are taken from the bf16-ROUNDED probabilities (the ones the PV product uses) with one v_dot2c_f32_bf16
         // against (1, 1) per pair: 16 VALU per tile instead of 31 adds, and O / l normalises exactly what was accumulated.
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
         float psum[2] = {0.f, 0.f};
         uint32_t pk[2][8];
 #pragma unroll
@@ -219,9 +217,9 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             for (int r = 0; r < 16; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c2, -m_run));
                 const float p1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c2, -m_run));
-                const uint32_t w = pack_bf16x2(p0, p1);
+                const uint32_t w = pack16x2<F16>(p0, p1);
                 pk[kb][r >> 1] = w;
-                psum[(r >> 1) & 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), ones, psum[(r >> 1) & 1], false);
+                psum[(r >> 1) & 1] = dot2_ones<F16>(w, psum[(r >> 1) & 1]);
             }
         l_run += psum[0] + psum[1];
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
                             (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk + 8 * (D * 2)));
                     }
                     const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                    o[d] = mfma16<F16>(vf, pf, o[d]);
                 }
             }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -350,8 +348,8 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 uint2_t w;
-                w.x = pack_bf16x2(o[d][4 * rq] * inv, o[d][4 * rq + 1] * inv);
-                w.y = pack_bf16x2(o[d][4 * rq + 2] * inv, o[d][4 * rq + 3] * inv);
+                w.x = pack16x2<F16>(o[d][4 * rq] * inv, o[d][4 * rq + 1] * inv);
+                w.y = pack16x2<F16>(o[d][4 * rq + 2] * inv, o[d][4 * rq + 3] * inv);
                 *reinterpret_cast<uint2_t *>(orow + d * 32 + 8 * rq + 4 * hh) = w;
             }
     }
@@ -383,7 +381,10 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
 #define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 2: LA(DD, 2); break; case 6: LA(DD, 6); break; \
     case 8: LA(DD, 8); break; case 10: LA(DD, 10); break; case 14: LA(DD, 14); break; case 3: LA(DD, 3); break; \
     default: LA(DD, 2); } } while (0)
-    if (D == 64) LV(64); else LV(128);
+    if (a.f16) {   // IEEE half: the default schedule only
+        if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, true>), grid, block, lds, st, a);
+        else VLLM_LAUNCH((attn_fwd_kernel<128, 2, true>), grid, block, lds, st, a);
+    } else if (D == 64) LV(64); else LV(128);
 #undef LV
 #undef LA
     VLLM_CHECK_LAUNCH("attn_fwd_kernel");
@@ -406,5 +407,20 @@ extern "C" int vllm_attn_fwd_qkvpacked_bf16(const uint16_t *qkv, uint16_t *out, 
     a.q_hs = a.k_hs = a.v_hs = D;
     a.B = B; a.S = S; a.H = H; a.nqt = 0;
     a.scale_log2e = softmax_scale * 1.4426950408889634f;
+    return attn_fwd_launch(a, D, (hipStream_t)stream);
+}
+// The same for IEEE-half qkv (the reference's FlashAttention accepts fp16 and bf16, flash_attention.py:39-41).
+extern "C" int vllm_attn_fwd_qkvpacked_f16(const uint16_t *qkv, uint16_t *out, int B, int S, int H, int D,
+                                           float softmax_scale, vllm_stream_t stream)
+{
+    AttnArgs a;
+    const long C = (long)H * D;
+    a.q = qkv; a.k = qkv ? qkv + C : nullptr; a.v = qkv ? qkv + 2 * C : nullptr; a.out = out;
+    a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * C;
+    a.q_ts = a.k_ts = a.v_ts = (int)(3 * C);
+    a.q_hs = a.k_hs = a.v_hs = D;
+    a.B = B; a.S = S; a.H = H; a.nqt = 0;
+    a.scale_log2e = softmax_scale * 1.4426950408889634f;
+    a.f16 = 1;
     return attn_fwd_launch(a, D, (hipStream_t)stream);
 }

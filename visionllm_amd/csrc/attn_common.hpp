@@ -33,6 +33,37 @@ __device__ __forceinline__ float halves_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-
+// The 16-bit element type of q / k / v / P / out is a template flag: bf16 (the vision tower's dtype) or IEEE half (the reference's
+// FlashAttention accepts both, flash_attention.py:39-41).  Same instruction count either way: 32x32x16 MFMA, packed
+// round-to-nearest-even conversion, dot2 against (1, 1) for the row sums; the LDS layouts and the transpose reads only see 16-bit words.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ f32x16_t mfma16(bf16x8_t a, bf16x8_t b, f32x16_t c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16x2(float a, float b)
+{
+    if constexpr (F16) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t v = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));   // round to nearest even
+    } else return pack_bf16x2(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ float dot2_ones(uint32_t w, float acc)
+{
+    if constexpr (F16) {
+        const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w), ones, acc, false);
+    } else {
+        const bf16x2v_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w), ones, acc, false);
+    }
+}
 
 }  // namespace vllm

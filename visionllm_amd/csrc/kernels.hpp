@@ -138,6 +138,7 @@ struct AttnArgs {
     int row0;                   // first query row of this launch (filled by the launcher)
     int no_trim;                // 1: process padding keys / padding query waves like live ones (A/B switch; launcher)
     float scale_log2e;
+    int f16 = 0;                // 1: q / k / v / out are IEEE half (flash_attention.py:39-41 accepts fp16 and bf16); fp32 softmax either way
 };
 int attn_fwd_launch(AttnArgs a, int D, hipStream_t st);
 

@@ -1,5 +1,5 @@
 """Bring-up hook B4: drop-in for the reference's ``FlashAttention`` module
-(VisionLLMv2/visionllmv2/model/internvit/flash_attention.py:14-76), backed by ``vllm_attn_fwd_qkvpacked_bf16``.
+(VisionLLMv2/visionllmv2/model/internvit/flash_attention.py:14-76), backed by ``vllm_attn_fwd_qkvpacked_bf16`` / ``_f16``.
 
 Only the call pattern the vision tower uses is supported -- ``forward(qkv[B,S,3,H,D], key_padding_mask=None,
 causal=False)`` in eval mode (``modeling_intern_vit.py:155-157``); anything else raises instead of silently computing
@@ -22,19 +22,15 @@ class FlashAttention(nn.Module):
             raise NotImplementedError("native FlashAttention: only dense non-causal qkv[B,S,3,H,D] (the ViT tile case)")
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("native FlashAttention: attention dropout is not implemented (inference path)")
-        if qkv.dtype == torch.float16:
-            # the reference accepts fp16 and bf16 (flash_attention.py:39-41: `assert qkv.dtype in [torch.float16, torch.bfloat16]`);
-            # the native kernel computes in bf16 only -- the dtype the vision tower runs in (modeling_visionllmv2.py casts it to bf16)
-            raise NotImplementedError("native FlashAttention: fp16 qkv is accepted by the reference (flash_attention.py:39-41) but not "
-                                      "implemented here; the vision tower runs in bf16 -- cast qkv to torch.bfloat16")
-        if qkv.dtype != torch.bfloat16 or not qkv.is_cuda or qkv.dim() != 5 or qkv.shape[2] != 3:
-            raise RuntimeError("native FlashAttention: qkv must be a bf16 CUDA tensor [B, S, 3, H, D] (flash_attention.py:39-41)")
+        # the reference accepts fp16 and bf16 (flash_attention.py:39-41: `assert qkv.dtype in [torch.float16, torch.bfloat16]`)
+        if qkv.dtype not in (torch.bfloat16, torch.float16) or not qkv.is_cuda or qkv.dim() != 5 or qkv.shape[2] != 3:
+            raise RuntimeError("native FlashAttention: qkv must be a bf16 / fp16 CUDA tensor [B, S, 3, H, D] (flash_attention.py:39-41)")
         qkv = qkv.contiguous()
         B, S, _, H, D = qkv.shape
         out = torch.empty((B, S, H, D), dtype=qkv.dtype, device=qkv.device)
         scale = self.softmax_scale if self.softmax_scale is not None else D ** -0.5
         with torch.cuda.device(qkv.device):
-            _lib.check(_lib.lib().vllm_attn_fwd_qkvpacked_bf16(_lib.ptr(qkv), _lib.ptr(out), B, S, H, D, float(scale),
-                                                               _lib.current_stream(qkv.device)),
-                       "vllm_attn_fwd_qkvpacked_bf16")
+            fn = _lib.lib().vllm_attn_fwd_qkvpacked_f16 if qkv.dtype == torch.float16 else _lib.lib().vllm_attn_fwd_qkvpacked_bf16
+            _lib.check(fn(_lib.ptr(qkv), _lib.ptr(out), B, S, H, D, float(scale), _lib.current_stream(qkv.device)),
+                       "vllm_attn_fwd_qkvpacked")
         return out, None

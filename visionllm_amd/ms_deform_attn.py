@@ -527,12 +527,27 @@ class MultiScaleDeformableAttention(nn.Module):
         attention_weights = attention_weights.softmax(-1).view(bs, num_query, self.num_heads, self.num_levels,
                                                                self.num_points)
         sampling_locations = _sampling_locations(reference_points, sampling_offsets, spatial_shapes, self.num_points)
-        output = MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
-                                                        attention_weights, self.im2col_step).to(value.dtype)
+        output = self._operator(value, spatial_shapes, level_start_index, sampling_locations, attention_weights)
         output = self.output_proj(output)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
         return self.dropout(output) + identity
+
+    def _operator(self, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+        # multi_scale_deform_attn.py:26 (custom_fwd(cast_inputs=torch.float32)): the operator runs in fp32 whatever the module's dtype
+        return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                                      attention_weights, self.im2col_step).to(value.dtype)
+
+
+class MultiScaleDeformableAttentionOptimized(MultiScaleDeformableAttention):
+    """The fork-added mmcv class (mmcv/ops/multi_scale_deform_attn_optimized.py:160-364, exported at ops/__init__.py:42): the same
+    module -- same parameters, same forward -- on the ``MultiScaleDeformableAttention`` extension's ABI (:18-21): no forced fp32 cast
+    (``custom_fwd`` without ``cast_inputs``, :27), sampling locations / attention weights follow value's dtype (:55-56), the gradients
+    are the extension's return value (:84-91).  fp32 / fp64 values run in their own dtype; for bf16 / fp16 values (which the
+    reference's extension does not dispatch: AT_DISPATCH_FLOATING_TYPES) the operator is evaluated in fp32, as everywhere else here."""
+
+    def _operator(self, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+        return _msda_apply_fp32(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, self.im2col_step)
 
 
 class GroundingDinoMultiscaleDeformableAttention(nn.Module):
