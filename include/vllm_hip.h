@@ -66,6 +66,9 @@ int vllm_device_info(char *name, int cap);
  * XCD rectangle; every order gives the same bits.  "gemm_skinny" (round 4; VLLM_GEMM_SKINNY): 1 (default) K = 256, N = 256 / 256 + 128
  * GEMMs with >= 4096 rows (the linears of a d_model = 256 deformable-attention layer) run on the weight-stationary streaming kernel
  * (gemm_skinny.hip); 0 on the 128 x 128 tile kernel -- the same bits either way.
+ * "dcnv3_bwd_tiled" (round 4; VLLM_DCNV3_BWD_TILED): 1 (default) vllm_dcnv3_backward_f32 with group channels 32 runs on the windowed
+ * kernel (grad_input as S^T x grad_out on the fp32 MFMA: msda_bwd_mfma.hip with the DCN flag), 0 on the gather kernel (global atomics
+ * per (point, corner, channel)); the same gradients to fp32 rounding.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */

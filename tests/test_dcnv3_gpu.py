@@ -192,6 +192,12 @@ def test_backward_vs_reference_autograd_golden(name):
     (1, 9, 9, 2, 8, 3, 1, 2, 2, 1.5),        # dilation 2, 2 lanes per group
     (3, 4, 5, 1, 4, 1, 1, 0, 1, 1.0),        # 1x1 kernel, one lane per group
     (2, 8, 8, 2, 1025, 3, 1, 1, 1, 2.0),     # the reference's gradcheck list ends with 1025 channels (test.py:257)
+    # group channels 32: the windowed kernel (msda_bwd_mfma.hip with the DCN flag: S^T x grad_out on the fp32 MFMA)
+    (1, 37, 29, 3, 32, 5, 1, 2, 1, 0.7),     # 5 x 5 = 25 points = 7 pseudo-levels of 4, ragged map
+    (2, 33, 50, 2, 32, 3, 2, 1, 1, 2.0),     # stride 2: the query grid (17 x 25) is not the input map
+    (1, 19, 23, 4, 32, 3, 1, 2, 2, 1.5),     # dilation 2, pad 2
+    (2, 9, 11, 2, 32, 1, 1, 0, 1, 1.0),      # 1 x 1 kernel: one point, three rejected slots
+    (1, 64, 64, 2, 32, 3, 1, 1, 1, 9.0),     # offset scale 9: windows beyond the staged (512) and the windowed (1024) limits
 ])
 def test_backward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
     """fp32 kernels against the fp32 C oracle: grad_offset / grad_mask per element (same terms, other summation order over the
@@ -218,6 +224,29 @@ def test_backward_f32_vs_oracle(N, H, W, G, C, k, s, p, d, scale):
     sc_o, sc_m = np.abs(ro).max() + 1e-12, np.abs(rm).max() + 1e-12
     np.testing.assert_allclose(gof.cpu().numpy(), ro, rtol=2e-4, atol=3e-6 * sc_o)
     np.testing.assert_allclose(gm.cpu().numpy(), rm, rtol=2e-4, atol=3e-6 * sc_m)
+
+
+def test_backward_windowed_kernel_agrees_with_gather_kernel():
+    """Option "dcnv3_bwd_tiled" 1 (default: the windowed MFMA kernel for group channels 32) against 0 (one thread group per (pixel,
+    group), global atomics per (point, corner, channel)): the same gradients to fp32 rounding, at an InternImage-like stage."""
+    from visionllm_amd import _lib
+    torch.manual_seed(3)
+    N, H, W, G, C, k = 2, 84, 84, 4, 32, 3
+    x = torch.randn(N, H, W, G * C, device=DEV)
+    off = torch.randn(N, H, W, G * k * k * 2, device=DEV) * 1.5
+    m = torch.softmax(torch.randn(N, H, W, G, k * k, device=DEV), -1).reshape(N, H, W, -1)
+    go = torch.randn(N, H, W, G * C, device=DEV)
+    res = {}
+    old = _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", 0)
+    try:
+        for v in (0, 1):
+            _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", v)
+            res[v] = A.dcnv3_backward(x, off, m, k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0, go)
+    finally:
+        _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", old)
+    for a, b, what in zip(res[0], res[1], ("grad_input", "grad_offset", "grad_mask")):
+        sc = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * sc, (what, float((a - b).abs().max()), sc)
 
 
 def test_backward_argument_checks():

@@ -38,6 +38,11 @@ def main():
         sec = timeit(lambda: A.dcnv3_forward(x, off, m, k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0))
         algo = (x.numel() * 2 + off.numel() + m.numel()) * 4   # input + output + offsets + mask, fp32
         print(json.dumps(dict(N=N, H=H, W=W, G=G, C=C, us=sec * 1e6, algo_GBs=algo / sec / 1e9, frac_of_8TBs=algo / sec / 8e12)))
+        if os.environ.get("DCN_BWD"):   # backward (round 4): input + grad_output read, grad_input accumulated, offsets / mask + their gradients
+            go = torch.randn(N, H, W, G * C, device=dev)
+            secb = timeit(lambda: A.dcnv3_backward(x, off, m, k, k, 1, 1, 1, 1, 1, 1, G, C, 1.0, go), iters=5)
+            algob = (x.numel() * 3 + 2 * (off.numel() + m.numel())) * 4
+            print(json.dumps(dict(backward=True, N=N, H=H, W=W, G=G, C=C, us=secb * 1e6, algo_GBs=algob / secb / 1e9, frac_of_8TBs=algob / secb / 8e12)))
 
 
 if __name__ == "__main__":

@@ -18,6 +18,8 @@
 // grad_input must be zero-filled by the caller (the Python mirror allocates it with torch.zeros, as the reference's host code
 // does with at::zeros_like); grad_offset / grad_mask are written completely (rejected points: zeros).
 #include "common.hpp"
+#include <stdlib.h>
+#include "kernels.hpp"
 #include "dcnv3_geo.hpp"
 
 namespace vllm {
@@ -229,6 +231,19 @@ int bwd_geo(Dcnv3Geo &q, int N, int H, int W, int G, int C, int kh, int kw, int 
 }  // namespace
 }  // namespace vllm
 
+namespace vllm {
+static int g_dcnv3_bwd_tiled = -1;
+int dcnv3_bwd_tiled()
+{
+    if (g_dcnv3_bwd_tiled < 0) {
+        const char *e = getenv("VLLM_DCNV3_BWD_TILED");
+        g_dcnv3_bwd_tiled = e ? atoi(e) != 0 : 1;
+    }
+    return g_dcnv3_bwd_tiled;
+}
+int dcnv3_bwd_tiled_set(int v) { const int old = dcnv3_bwd_tiled(); g_dcnv3_bwd_tiled = v != 0; return old; }
+}  // namespace vllm
+
 using namespace vllm;
 
 extern "C" int vllm_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output, int N,
@@ -240,6 +255,10 @@ extern "C" int vllm_dcnv3_backward_f32(const float *input, const float *offset, 
     if (int e = bwd_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
     if (N == 0) return VLLM_OK;
     VLLM_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "dcnv3_backward_f32: null pointer");
+    // group channels 32 (InternImage-H style stages): the windowed kernel -- grad_input as S^T x grad_out on the fp32 MFMA, one global
+    // atomic per (window pixel, channel) instead of one per (point, corner, channel) (msda_bwd_mfma.hip, template flag DCN)
+    if (dcnv3_bwd_tiled() && dcnv3_bwd_mfma_takes(q) && aligned16(input) && aligned16(grad_output) && (reinterpret_cast<uintptr_t>(offset) & 7u) == 0)
+        return dcnv3_bwd_mfma_launch(input, offset, mask, grad_output, q, offset_scale, grad_input, grad_offset, grad_mask, (hipStream_t)stream);
     return dcnv3_bwd_launch<float>(input, offset, mask, grad_output, q, offset_scale, grad_input, grad_offset, grad_mask, (hipStream_t)stream);
 }
 

@@ -80,6 +80,12 @@ bool gemm_skinny_takes(int epi, const GemmArgs &a);
 int gemm_skinny_launch(int epi, const GemmArgs &a, hipStream_t st);
 int gemm_skinny_enabled();
 int gemm_skinny_set(int v);
+struct Dcnv3Geo;
+bool dcnv3_bwd_mfma_takes(const Dcnv3Geo &q);   // msda_bwd_mfma.hip (template flag DCN): fp32, group channels 32
+int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *mask, const float *grad_out, const Dcnv3Geo &q,
+                          float offset_scale, float *grad_input, float *grad_offset, float *grad_mask, hipStream_t st);
+int dcnv3_bwd_tiled();       // VLLM_DCNV3_BWD_TILED / vllm_set_option("dcnv3_bwd_tiled")
+int dcnv3_bwd_tiled_set(int v);
 int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 

@@ -17,12 +17,21 @@
 // back to direct global atomics per (point, corner, channel).  grad_sampling_loc and grad_attn_weight are computed as
 // before (value corners from global memory / L2, one owner per element, plain stores).
 //
+// Round 4: the SAME kernel serves the DCNv3 backward for group channels 32 (template flag DCN; dcnv3_im2col_cuda.cuh:86-146, 279-857):
+// a DCNv3 call is this operator with ONE value map (the input), heads = groups, queries = output pixels, attention weights = the
+// mask, and kh * kw sampling points per query that are run as ceil(kh kw / 4) pseudo-levels of 4 points (3 for the 3 x 3 kernel;
+// slots beyond kh kw get a rejected location).  What differs is confined to four places: the geometry set-up, where a point's
+// location comes from (offset -> location in the reference's own operation order, dcnv3_im2col_cuda.cuh:319-336, so that a point
+// lands in the same cell as in the reference), the scale of the location gradient (offset_scale instead of W / H), and the
+// indexing of the three per-point outputs.
+//
 // Follows ms_deform_im2col_cuda.cuh:87-161 (col2im bilinear: grad_value scatter, grad_sampling_loc, grad_attn_weight) and
 // the reductions of :301-360.  Summation order differs from the reference's atomics (as every atomic scatter does); tests
 // compare against the oracle with the tolerance of the other backward kernels.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "msda_sample.hpp"
+#include "dcnv3_geo.hpp"
 
 // Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (large-window) atomics, 4: no S scatter,
 // 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no MFMA, 64: no grad_value rounds at all.
@@ -68,12 +77,15 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float x)   // x + (
 // the upper quad's sum down: lane i reads lane i + 4)
 __device__ __forceinline__ float sum8(float x) { return dpp_add<0x104>(dpp_add<0x4e>(dpp_add<0xb1>(x))); }
 
+template <bool DCN>
 __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out, int B, int S, int M,
-    int L, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attw)
+    int L, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attw, const Dcnv3Geo dq,
+    const float dscale)
 {
     constexpr int D = 32, PT = 4;
+    const int DP = DCN ? dq.kh * dq.kw : 0;   // DCNv3: sampling points per (pixel, group); L = (DP + 3) / 4 pseudo-levels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *st = reinterpret_cast<float *>(smem);                                   // S^T [128 queries][BT_RP]: weight of query q on window pixel p of this round
     float2_t *s_loc = reinterpret_cast<float2_t *>(smem + BT_LDS_WIN);             // [128 queries][4 points]
@@ -90,7 +102,13 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
     const int slot0 = tid >> 3;   // query slot inside a pass
     const long MD = (long)M * D;
 
-    if (tid == 0) {
+    if (DCN) {
+        if (tid == 0) {
+            for (int l = 0; l < L; ++l) { s_H[l] = dq.H; s_W[l] = dq.W; s_q0[l] = 0; s_v0[l] = 0; s_tc[l] = 0; }
+            s_tc[L] = ((dq.Ho + BT_TH - 1) / BT_TH) * ((dq.Wo + BT_TW - 1) / BT_TW);
+            s_geo_ok = 1;
+        }
+    } else if (tid == 0) {
         long cum = 0;
         int tc = 0;
         for (int l = 0; l < L; ++l) {
@@ -123,7 +141,11 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
         const int m = (int)(bm % M);
         const long b = bm / M;
         int qH, qW, q0, ty, tx;
-        if (geo) {
+        if (DCN) {   // the query grid is the OUTPUT map
+            qH = dq.Ho; qW = dq.Wo; q0 = 0;
+            const int txn = (qW + BT_TW - 1) / BT_TW;
+            ty = t / txn; tx = t - ty * txn;
+        } else if (geo) {
             int lq = 0;
             while (lq + 1 < L && s_tc[lq + 1] <= t) ++lq;
             qH = s_H[lq]; qW = s_W[lq]; q0 = s_q0[lq];
@@ -162,10 +184,45 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
         const long lq_pair = pair_of(tid >> 1, lq_ok);
         const long aq_pair = pair_of(tid & (BT_NQ - 1), aq_ok);
         const bool lthr = tid < BT_NQ * 2;
+        // locations (x, y) of two points of a query per thread (tid < 256) and the 4 weights of a query (tid < 128) of level l.
+        // DCNv3: offsets -> locations in input pixels, the reference's arithmetic (dcnv3_im2col_cuda.cuh:300-334: p0 = centre of the
+        // kernel footprint, point (i, j) of the kw x kh grid in w-major order); a slot beyond kh * kw gets (-2, -2): rejected.
+        float dp0w = 0.f, dp0h = 0.f;
+        if (DCN) {
+            const int slot = tid >> 1, y = ty * BT_TH + slot / BT_TW, x = tx * BT_TW + slot % BT_TW;
+            const int p0_w = ((dq.dw * (dq.kw - 1)) >> 1) - dq.pw + x * dq.sw, p0_h = ((dq.dh * (dq.kh - 1)) >> 1) - dq.ph + y * dq.sh;
+            // (every product rounded on its own -- mul_rn, msda_sample.hpp: the backend would fuse mul + add into one fma, and one ulp
+            //  of a location of ~100 pixels is 8e-6 of a pixel: visible in the bilinear weights)
+            dp0w = (float)p0_w - mul_rn((float)((dq.dw * (dq.kw - 1)) >> 1), dscale);
+            dp0h = (float)p0_h - mul_rn((float)((dq.dh * (dq.kh - 1)) >> 1), dscale);
+        }
+        auto load_loc = [&](int l) -> float4_t {
+            if (!DCN) return *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l) * (PT * 2) + (tid & 1) * 4);
+            float4_t r = {-2.f, -2.f, -2.f, -2.f};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = l * PT + (tid & 1) * 2 + e;
+                if (j < DP) {
+                    const float2_t o2 = *reinterpret_cast<const float2_t *>(loc + (lq_pair * DP + j) * 2);
+                    const int i = j / dq.kh, jj = j - i * dq.kh;
+                    r[2 * e] = dp0w + mul_rn((float)(i * dq.dw) + o2.x, dscale);
+                    r[2 * e + 1] = dp0h + mul_rn((float)(jj * dq.dh) + o2.y, dscale);
+                }
+            }
+            return r;
+        };
+        auto load_aw = [&](int l) -> float4_t {
+            if (!DCN) return *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l) * PT);
+            float4_t r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (l * PT + e < DP) r[e] = attw[aq_pair * DP + l * PT + e];
+            return r;
+        };
         float4_t nloc = {0.f, 0.f, 0.f, 0.f};
-        if (lthr) nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + 0) * (PT * 2) + (tid & 1) * 4);
+        if (lthr) nloc = load_loc(0);
         float4_t naw = {0.f, 0.f, 0.f, 0.f};
-        if (tid < BT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + 0) * PT);
+        if (tid < BT_NQ) naw = load_aw(0);
 
         BT_TICK(0)   // item set-up: decode, grad_output / first level's locations requested
         for (int l = 0; l < L; ++l) {
@@ -177,8 +234,8 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             if (lthr) reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
             if (tid < BT_NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
             if (l + 1 < L) {
-                if (lthr) nloc = *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l + 1) * (PT * 2) + (tid & 1) * 4);
-                if (tid < BT_NQ) naw = *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l + 1) * PT);
+                if (lthr) nloc = load_loc(l + 1);
+                if (tid < BT_NQ) naw = load_aw(l + 1);
             }
             __syncthreads();
             BT_TICK(1)   // two barriers around the hand-over of this level's locations / weights
@@ -192,7 +249,13 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
                 const int slot = p * BT_QPP + slot0;
                 const float2_t xy = s_loc[slot * PT + kpt];
                 awp[p] = s_aw[slot * PT + kpt];
-                const SamplePoint<float> sp = sample_point<float>(xy.x, xy.y, H, W);
+                SamplePoint<float> sp;
+                if (DCN) {   // xy is the location in input pixels already; acceptance and floor as dcnv3_im2col_cuda.cuh:335-336, 92-93
+                    sp.h_im = xy.y; sp.w_im = xy.x;
+                    sp.ok = xy.y > -1.f && xy.x > -1.f && xy.y < (float)H && xy.x < (float)W;
+                    sp.h_low = sp.ok ? (int)floorf(xy.y) : 0;
+                    sp.w_low = sp.ok ? (int)floorf(xy.x) : 0;
+                } else sp = sample_point<float>(xy.x, xy.y, H, W);
                 him[p] = sp.h_im; wim[p] = sp.w_im; hlo[p] = sp.h_low; wlo[p] = sp.w_low;
                 okp[p] = (sp.ok && qok[p] && H > 0 && W > 0) ? 1 : 0;   // (empty level: no corner inside, nothing to do)
                 if (okp[p]) {
@@ -214,7 +277,18 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             const int y1 = -min(min(s_red[0][1], s_red[1][1]), min(s_red[2][1], s_red[3][1]));
             const int x0w = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
             const int x1w = -min(min(s_red[0][3], s_red[1][3]), min(s_red[2][3], s_red[3][3]));
-            if (y1 < 0) continue;   // no accepted point at this level (block-uniform): all three gradients stay zero
+            if (y1 < 0) {   // no accepted point at this level (block-uniform): MSDA: all three gradients stay zero (the caller's fill)
+                if (DCN && sub == 0) {   // DCNv3 writes every slot of grad_offset / grad_mask
+#pragma unroll
+                    for (int p = 0; p < BT_NPASS; ++p)
+                        for (int K = 0; K < PT; ++K)
+                            if (qok[p] && l * PT + K < DP) {
+                                const long pi = qidx[p] * DP + l * PT + K;
+                                grad_attw[pi] = 0.f; grad_loc[2 * pi] = 0.f; grad_loc[2 * pi + 1] = 0.f;
+                            }
+                }
+                continue;
+            }
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
@@ -272,17 +346,17 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
             }                                                                                                          \
             const float val = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4;                                                   \
             g_aw += top * val;                                                                                         \
-            g_x += (float)W * gww * tgv;                                                                               \
-            g_y += (float)H * ghw * tgv;                                                                               \
+            g_x += (DCN ? dscale : (float)W) * gww * tgv;                                                              \
+            g_y += (DCN ? dscale : (float)H) * ghw * tgv;                                                              \
         }                                                                                                              \
         _Pragma("unroll") for (int o = 4; o > 0; o >>= 1) {                                                            \
             g_aw += __shfl_xor(g_aw, o); g_x += __shfl_xor(g_x, o); g_y += __shfl_xor(g_y, o);                         \
         }                                                                                                              \
-        if (sub == 0 && pok && !(BT_ABL & 16)) {   /* rejected points keep the caller's zero fill */                                     \
-            const long pi = (qidx[p] * L + l) * PT + K;                                                                \
-            grad_attw[pi] = g_aw;                                                                                      \
-            grad_loc[2 * pi] = g_x;                                                                                    \
-            grad_loc[2 * pi + 1] = g_y;                                                                                \
+        if (sub == 0 && (DCN ? (qok[p] && l * PT + K < DP) : pok) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
+            const long pi = DCN ? qidx[p] * DP + l * PT + K : (qidx[p] * L + l) * PT + K;                              \
+            grad_attw[pi] = pok ? g_aw : 0.f;                                                                          \
+            grad_loc[2 * pi] = pok ? g_x : 0.f;                                                                        \
+            grad_loc[2 * pi + 1] = pok ? g_y : 0.f;                                                                    \
         }                                                                                                              \
     }
             // Staged window (the common case): the per-point gradients only need the four dot products  d_i = <grad_out, corner i>
@@ -310,11 +384,11 @@ __global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
         float d4 = g[0] * v4[0] + g[1] * v4[1] + g[2] * v4[2] + g[3] * v4[3];                                          \
         d1 = k1 ? d1 : 0.f; d2 = k2 ? d2 : 0.f; d3 = k3 ? d3 : 0.f; d4 = k4 ? d4 : 0.f;                                \
         d1 = sum8(d1); d2 = sum8(d2); d3 = sum8(d3); d4 = sum8(d4);                                                    \
-        if (sub == 0 && pok && !(BT_ABL & 16)) {   /* rejected points keep the caller's zero fill */                   \
-            const long pi = (qidx[p] * L + l) * PT + K;                                                                \
-            grad_attw[pi] = ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4);                     \
-            grad_loc[2 * pi] = (float)W * aw * (hh * (d2 - d1) + lh * (d4 - d3));                                      \
-            grad_loc[2 * pi + 1] = (float)H * aw * (hw * (d3 - d1) + lw * (d4 - d2));                                  \
+        if (sub == 0 && (DCN ? (qok[p] && l * PT + K < DP) : pok) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
+            const long pi = DCN ? qidx[p] * DP + l * PT + K : (qidx[p] * L + l) * PT + K;                              \
+            grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;         \
+            grad_loc[2 * pi] = pok ? (DCN ? dscale : (float)W) * aw * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f;         \
+            grad_loc[2 * pi + 1] = pok ? (DCN ? dscale : (float)H) * aw * (hw * (d3 - d1) + lw * (d4 - d2)) : 0.f;     \
         }                                                                                                              \
     }
             if (use_stage) {
@@ -418,13 +492,40 @@ int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_
     const int cus = device_cus();
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)BT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BT_LDS);
     }
     const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
-    VLLM_LAUNCH(msda_bwd_mfma_kernel, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
-                Lq, gv, gl, gw);
+    VLLM_LAUNCH(msda_bwd_mfma_kernel<false>, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
+                Lq, gv, gl, gw, Dcnv3Geo{}, 0.f);
     VLLM_CHECK_LAUNCH("msda_bwd_mfma_kernel");
+    return VLLM_OK;
+}
+
+// DCNv3 backward, fp32, group channels 32, kh * kw <= 4 * BT_MAXL: the kernel above on the DCNv3 geometry.  grad_input must be
+// zero-filled by the caller (it is accumulated); grad_offset / grad_mask are written completely.
+bool dcnv3_bwd_mfma_takes(const Dcnv3Geo &q)
+{
+    return q.C == 32 && q.kh * q.kw >= 1 && q.kh * q.kw <= 4 * BT_MAXL && (long)q.N * q.H * q.W * q.G * q.C < (1L << 40);
+}
+int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *mask, const float *grad_out, const Dcnv3Geo &q,
+                          float offset_scale, float *grad_input, float *grad_offset, float *grad_mask, hipStream_t st)
+{
+    const int cus = device_cus();
+    static unsigned long long attr_mask = 0;
+    if (first_use_on_device(&attr_mask)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)BT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)BT_LDS);
+    }
+    const int grid = (cus / 8) * 8 * 2;
+    const int L = (q.kh * q.kw + 3) / 4;
+    VLLM_LAUNCH(msda_bwd_mfma_kernel<true>, dim3(grid), dim3(BT_THREADS), BT_LDS, st, input, nullptr, nullptr, offset, mask, grad_out, q.N,
+                q.H * q.W, q.G, L, q.Ho * q.Wo, grad_input, grad_offset, grad_mask, q, offset_scale);
+    VLLM_CHECK_LAUNCH("msda_bwd_mfma_kernel<dcnv3>");
     return VLLM_OK;
 }
 
