@@ -69,6 +69,9 @@ int vllm_device_info(char *name, int cap);
  * "dcnv3_bwd_tiled" (round 4; VLLM_DCNV3_BWD_TILED): 1 (default) vllm_dcnv3_backward_f32 with group channels 32 runs on the windowed
  * kernel (grad_input as S^T x grad_out on the fp32 MFMA: msda_bwd_mfma.hip with the DCN flag), 0 on the gather kernel (global atomics
  * per (point, corner, channel)); the same gradients to fp32 rounding.
+ * "gemm_half_tail" (round 4; VLLM_GEMM_HALF_TAIL): 1 (default) the persistent 8-phase GEMM runs the tiles of its last, incomplete round
+ * as two half-height tiles each when they then still fit the grid (qkv at 40 ViT-L tiles: 4.27 rounds of work in 5 -> 4 + a half-tile
+ * round); 0 whole tiles.  The same bits either way.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */
@@ -281,6 +284,7 @@ int vllm_gemm_bf16(const uint16_t *X, const uint16_t *W, const uint16_t *bias, u
  * vllm_bridge_forward reserve theirs inside their workspace. */
 long vllm_gemm_scratch_bytes(void);
 long vllm_gemm_sk_launches(void);   /* GEMM launches of this process that took the stream-K tail (tests / tuning) */
+long vllm_gemm_half_tail_launches(void);   /* ... of the persistent schedule whose last round ran as half-height tiles (round 4) */
 long vllm_gemm_persistent_launches(void);   /* GEMM launches of this process that took the persistent 8-phase schedule (tests / tuning) */
 int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
                       int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,

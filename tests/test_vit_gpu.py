@@ -562,6 +562,50 @@ def test_attention_schedule_variants(variant, D, S):
     close(out, _attn_ref(qkv.cpu(), H, D, D ** -0.5), 1.5e-2, f"attention variant {variant}")
 
 
+@pytest.mark.parametrize("M,N,K,epi,expect_half", [
+    (40 * 577, 3072, 1024, 0, True),     # qkv: 1092 tiles = 4 rounds + 68 -> 136 half tiles
+    (40 * 577, 1024, 1024, 3, False),    # proj + residual + LayerScale: the residual instantiations keep whole tiles (register limit)
+    (40 * 577, 1024, 4096, 3, False),    # fc2 + residual
+    (40 * 577, 4096, 1024, 2, False),    # fc1 + quick-GELU: 1456 tiles = 5 rounds + 176: does not fit the grid as half tiles
+    (32 * 577, 3072, 1024, 1, True),     # the 32-tile batch, GELU: 876 tiles = 3 rounds + 108
+    (5 * 1025 + 3, 3200, 3200, 3, None), # InternViT-6B proj at 5 tiles, ragged M, N not a multiple of 256
+    (2 * 256 * 4 + 130, 2048, 128, 0, None),   # two K tiles only: the half tile's pipeline right behind the prologue
+])
+def test_gemm_half_height_tail_round_is_bit_identical(M, N, K, epi, expect_half):
+    """Round 4: the persistent schedule runs the tiles of its last, incomplete round as two half-height tiles each (option
+    "gemm_half_tail") when they then still fit the grid -- K tiles of two quadrants, three refilled half-tiles, its own counted wait.
+    The tile height does not enter an output element's arithmetic: the same bits as whole tiles; repeated runs agree (race screen of
+    the half tile's refill pipeline); the counter says whether the path under test ran."""
+    torch.manual_seed(M + N + epi)
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = bf(torch.randn(N, device=DEV))
+    res = bf(torch.randn(M, N, device=DEV)) if epi == 3 else None
+    scale = bf(torch.rand(N, device=DEV) + 0.5) if epi == 3 else None
+    L = _lib.lib()
+
+    def run(half):
+        old = L.vllm_set_option(b"gemm_half_tail", half)
+        try:
+            y = torch.full((M + 7, N), 7.0, dtype=torch.bfloat16, device=DEV)       # canary rows behind the output
+            before = L.vllm_gemm_half_tail_launches()
+            _lib.check(L.vllm_gemm_bf16(P(x), P(w), P(b), P(y), M, N, K, K, K, N, epi, P(scale) if scale is not None else None,
+                                        P(res) if res is not None else None, N, 0, stream()))
+            torch.cuda.synchronize()
+            return y, L.vllm_gemm_half_tail_launches() - before
+        finally:
+            L.vllm_set_option(b"gemm_half_tail", old)
+    y0, n0 = run(0)
+    y1, n1 = run(1)
+    assert n0 == 0
+    if expect_half is not None:
+        assert (n1 == 1) == expect_half, n1
+    assert torch.isfinite(y1.float()).all() and bool((y1[M:] == 7.0).all())
+    assert torch.equal(y0, y1), float((y0.float() - y1.float()).abs().max())
+    for _ in range(5):
+        assert torch.equal(run(1)[0], y1)
+
+
 def test_attention_rejects_head_dim():
     qkv = bf(torch.zeros(1, 4, 3, 2, 32, device=DEV))
     out = torch.empty(1, 4, 2, 32, dtype=torch.bfloat16, device=DEV)

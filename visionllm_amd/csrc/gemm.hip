@@ -348,6 +348,7 @@ extern "C" int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uin
 extern "C" long vllm_gemm_scratch_bytes(void) { return SK_SCRATCH_BYTES; }
 namespace vllm { long gemm256_sk_launches(); }
 extern "C" long vllm_gemm_sk_launches(void) { return vllm::gemm256_sk_launches(); }
+extern "C" long vllm_gemm_half_tail_launches(void) { return vllm::gemm256p_half_launches(); }
 namespace vllm { long gemm256p_launches(); }
 extern "C" long vllm_gemm_persistent_launches(void) { return vllm::gemm256p_launches(); }
 

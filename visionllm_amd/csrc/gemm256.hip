@@ -862,7 +862,14 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     // under the next tile's main loop: ~10 % per tile (tools/gemm_persist_ab.py), more than the stream-K tail recovers, so it
     // is asked first, with the tile height that needs fewer whole rounds
     if (!mf32) {
-        auto rounds = [&](int mt_rows) { return (double)ceil_div((long)ceil_div(a.M, 64 * mt_rows) * a.nt, (long)cus) * (mt_rows == 4 ? 100.0 : 87.0); };
+        // (a last round whose tiles, cut in two, still fit the grid runs as half-height tiles in the persistent kernel.  Measured: 0.9 of a
+        //  round, not 0.5 -- a half tile still refills three of the four half-tiles per K tile, and the refills pace the loop)
+        auto rounds = [&](int mt_rows) {
+            const long T_ = (long)ceil_div(a.M, 64 * mt_rows) * a.nt, full = T_ / cus, r_ = T_ % cus;
+            const double c_ = mt_rows == 4 ? 100.0 : 87.0;
+            const double last = r_ == 0 ? 0.0 : (gemm_half_tail() && epi != EPI_RESIDUAL && full >= 1 && 2 * r_ <= cus) ? 0.9 : 1.0;
+            return ((double)full + last) * c_;
+        };
         int pmt = rounds(3) < rounds(4) ? 3 : 4;
         if (a.variant256 == 3 || a.variant256 == 4) pmt = a.variant256;
         GemmArgs b = a;

@@ -96,7 +96,10 @@ __device__ __forceinline__ void store_piece(u32x4_t &o, __amdgpu_buffer_rsrc_t r
         __builtin_amdgcn_sched_barrier(0);\
     } while (0)
 
-template <int EPI, int MT, bool LNC, bool STATS = false>
+// HALFT: the instantiation that can run the last round as half-height tiles (see the tile loop).  A separate instantiation because
+// the second K loop costs the whole-tile loop registers (210 -> 237 VGPRs, 4 -> 33 spilled SGPRs) and 2 % of its speed (fc1, same box:
+// 169 -> 173 us): launches whose last round stays whole keep the kernel they had.
+template <int EPI, int MT, bool LNC, bool STATS = false, bool HALFT = false>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a)
 {
     static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU || (EPI == EPI_RESIDUAL && !LNC),
@@ -288,13 +291,29 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
 
+    // ---- the block's tiles: iteration `it` is tile blockIdx.x + it * G in the whole rounds.  The LAST, incomplete round (r = T % G
+    // tiles) has two forms: one tile per block for the first r blocks (whole tiles), or -- half_tail (round 4; the launcher sets it
+    // when 2 r <= G) -- HALF tiles: block b < 2 r takes rows [h HM, (h + 1) HM) of tile full_tiles + b % r, h = b / r: the round then
+    // costs a half tile's time (K tiles of two quadrants instead of four, three refilled half-tiles instead of four) instead of a
+    // whole one while most of the CUs idle (qkv at 40 tiles: 4.27 rounds of work in 5).  Same arithmetic per output element.
+    const int n_whole = T / G, r_last = T - n_whole * G;
+    // (not in the residual instantiations: their 256-row form sits at the register limit -- with the second K loop it spills, and a
+    //  spilled register that is the destination of a residual load still in flight is stored before the load lands: run-to-run
+    //  different results, seen on hardware.  Their launches keep whole tiles.)
+    constexpr bool HT = HALFT && !RES;
+    const bool half_tail = HT && a.half_tail != 0 && r_last > 0;
+    const int n_it = n_whole + ((int)blockIdx.x < (half_tail ? 2 * r_last : r_last) ? 1 : 0);
+    auto locate = [&](int it, int &mm, int &nn) -> bool {   // -> is iteration `it` a half tile?
+        if (it < n_whole || !half_tail) { coords((int)blockIdx.x + it * G, mm, nn); return false; }
+        const int h = (int)blockIdx.x / r_last;
+        coords(full_tiles + ((int)blockIdx.x - h * r_last), mm, nn);
+        mm += h * HM;
+        return true;
+    };
     // ---- block prologue: the vectors of the first tile, its K tile 0 complete in stage 0, K tile 1's A0, B1, A1 in flight ----
-    int tile = blockIdx.x;
-    coords(tile, m0, n0);
-    {
-        const int nxt = tile + G;
-        if (nxt < T) coords(nxt, m0n, n0n); else { m0n = m0; n0n = n0; }
-    }
+    int it_cur = 0;
+    bool half_cur = locate(0, m0, n0), half_nxt = false;
+    if (n_it > 1) half_nxt = locate(1, m0n, n0n); else { m0n = m0; n0n = n0; }
     for (int i = tid; i < (P_LDS - P_RING) / 4; i += P_THREADS) reinterpret_cast<unsigned *>(smem + P_RING)[i] = 0u;   // (missing vectors read as zeros)
     __syncthreads();
     issue_vectors(m0, n0, 0);
@@ -343,6 +362,45 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             P_BARRIER();
             if (a.prof && t < 4) t_k[t] = (unsigned)__builtin_amdgcn_s_memtime();   // (clock: the first K tiles of a tile, one by one)
         };
+        // a HALF tile's K tile: quadrants (A0,B0), (A0,B1) only.  Phases 1 and 2 are the full tile's (same refills: B0 of the other stage
+        // with K tile t + 1, A0 of this stage with t + 2); the third phase has no MFMA section: it refills B1 (read for the last time in
+        // phase 2, two barriers ago: the full tile's distance) and retires every refill but the newest two half-tiles -- B0 of K tile
+        // t + 1 has landed when the next K tile starts, as behind the full tile's phase 4.  A1 is never read and never refilled.
+        auto k_tile_half = [&](int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int s = (t + par) & 1;
+            const char *st = smem + s * P_STAGE;
+            read_x(st + P_A0); read_w_into(st + P_B0, wf);
+            issue_B(0, s ^ 1, t + 1);
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(0, wf, FIRST);
+            P_BARRIER();
+            read_w_into(st + P_B1, wg);
+            issue_A(0, s, t + 2);
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_MMA(1, wg, FIRST);
+            P_BARRIER();
+            issue_B(1, s, t + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            P_WAIT_LGKM0(); P_BARRIER();
+            P_BARRIER();
+            if (a.prof && t < 4) t_k[t] = (unsigned)__builtin_amdgcn_s_memtime();
+        };
+        if (HT && half_cur) {
+            // (no early request of the residual pieces here: registers in flight must not be DEFINED on both sides of a join -- where
+            //  the allocator picks different registers it copies them while the load is still out; a half tile asks for its pieces at
+            //  the start of its epilogue, inside one block with their wait)
+            k_tile_half(0, std::true_type{});
+#pragma unroll 1
+            for (int t = 1; t < nk; ++t) k_tile_half(t, std::false_type{});
+            // (quadrants 2, 3 are not computed: DEFINE them, or their registers stay live around the whole tile loop -- +64 VGPRs, spills)
+#pragma unroll
+            for (int q = 2; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[q][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        } else {
         k_tile(0, std::true_type{});
         if constexpr (RES) {
             // the residual pieces of quadrant 0 are requested in front of the last K tile (more than one quadrant's worth does
@@ -357,14 +415,15 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
 #pragma unroll 1
             for (int t = 1; t < nk; ++t) k_tile(t, std::false_type{});
         }
+        }
         if (wr == 0) P_BARRIER();   // level again
         par = (par + nk) & 1;
         const unsigned t_b = a.prof ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
 
         // ---- between two tiles: the ring already holds the next tile's K tile 0 (its K tile 1 is in flight) ----
-        const int nxt = tile + G;
-        const bool more = nxt < T;
+        const bool more = it_cur + 1 < n_it;
         const int buf = it & 1;
+        const int nq = (HT && half_cur) ? 2 : 4;   // quadrants this tile stores (a half tile: the A0 row half only)
         if (more) issue_vectors(m0n, n0n, buf ^ 1);   // (that buffer was last read in the epilogue before the main loop just finished)
         if constexpr (LNC) {
             // the row table {r, -r mean} of this tile from its statistics (Chan's update in a fixed order, constants from the
@@ -416,7 +475,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
 #pragma unroll
             for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) if (q < 2 || nq == 4) {   // (q < 2: compile-time true -- no join inside the in-flight windows above)
                 const int qi = q >> 1, qj = q & 1;
                 if (q == 1) {
                     if constexpr (MT == 4)
@@ -530,7 +589,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
 #pragma unroll
             for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) if (q < 2 || nq == 4) {   // (q < 2: compile-time true -- no join inside the in-flight windows above)
                 const int qi = q >> 1, qj = q & 1;
                 EpiCols cols[2];
                 f32x4_t csum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -578,11 +637,8 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             pf[3] += t_k[0] - t_a; pf[4] += t_k[1] - t_k[0]; pf[5] += t_k[2] - t_k[1]; pf[6] += t_k[3] - t_k[2];
         }
         if (!more) break;
-        tile = nxt; m0 = m0n; n0 = n0n;
-        {
-            const int n2 = tile + G;
-            if (n2 < T) coords(n2, m0n, n0n); else { m0n = m0; n0n = n0; }
-        }
+        ++it_cur; m0 = m0n; n0 = n0n; half_cur = half_nxt;
+        if (it_cur + 1 < n_it) half_nxt = locate(it_cur + 1, m0n, n0n); else { m0n = m0; n0n = n0; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
     if (a.prof && wave == 0 && lane == 0) {
@@ -619,6 +675,18 @@ bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
     return true;
 }
 
+static long g_p_half_launches = 0;   // launches whose last round ran as half-height tiles (tests assert the path they mean to cover ran)
+long gemm256p_half_launches() { return g_p_half_launches; }
+static int g_half_tail = -1;
+int gemm_half_tail()
+{
+    if (g_half_tail < 0) {
+        const char *e = getenv("VLLM_GEMM_HALF_TAIL");
+        g_half_tail = e ? atoi(e) != 0 : 1;
+    }
+    return g_half_tail;
+}
+int gemm_half_tail_set(int v) { const int old = gemm_half_tail(); g_half_tail = v != 0; return old; }
 static long g_p_launches = 0;   // (vllm_gemm_persistent_launches: tests assert the path they mean to cover ran)
 long gemm256p_launches() { return g_p_launches; }
 
@@ -635,21 +703,30 @@ int gemm256p_launch(int epi, int MT, const GemmArgs &a_, int cus, hipStream_t st
     }
     ++g_p_launches;
     const long T = (long)a.mt * a.nt;
+    {   // half-height tiles in the last, incomplete round (kernel comment): when its tiles, cut in two, still fit the grid
+        const long r = T % cus;
+        a.half_tail = (gemm_half_tail() && epi != EPI_RESIDUAL && T >= cus && r > 0 && 2 * r <= cus) ? 1 : 0;
+        if (a.half_tail) ++g_p_half_launches;
+    }
     const dim3 grid((unsigned)std::min<long>(T, cus)), block(P_THREADS);
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
 #define SETATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 4, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS)
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
+                      if (E != EPI_RESIDUAL) { \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 4, L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 3, L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); }
         SETATTR(EPI_BIAS, false); SETATTR(EPI_GELU, false); SETATTR(EPI_QUICK_GELU, false);
         SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true); SETATTR(EPI_RESIDUAL, false);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
 #undef SETATTR
     }
-#define LAUNCH(E) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true>), grid, block, P_LDS, st, a); \
-                                       else VLLM_LAUNCH((gemm256p_kernel<E, 3, true>), grid, block, P_LDS, st, a); } \
-                       else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false>), grid, block, P_LDS, st, a); \
-                              else VLLM_LAUNCH((gemm256p_kernel<E, 3, false>), grid, block, P_LDS, st, a); } } while (0)
+#define LAUNCH_H(E, H) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true, false, H>), grid, block, P_LDS, st, a); \
+                                            else VLLM_LAUNCH((gemm256p_kernel<E, 3, true, false, H>), grid, block, P_LDS, st, a); } \
+                            else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false, false, H>), grid, block, P_LDS, st, a); \
+                                   else VLLM_LAUNCH((gemm256p_kernel<E, 3, false, false, H>), grid, block, P_LDS, st, a); } } while (0)
+#define LAUNCH(E) do { if (a.half_tail) LAUNCH_H(E, true); else LAUNCH_H(E, false); } while (0)
     if (epi == EPI_RESIDUAL && a.ln_out) {
         if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), grid, block, P_LDS, st, a);
         else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), grid, block, P_LDS, st, a);
@@ -658,6 +735,7 @@ int gemm256p_launch(int epi, int MT, const GemmArgs &a_, int cus, hipStream_t st
         else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false>), grid, block, P_LDS, st, a);
     } else if (epi == EPI_BIAS) LAUNCH(EPI_BIAS); else if (epi == EPI_GELU) LAUNCH(EPI_GELU); else LAUNCH(EPI_QUICK_GELU);
 #undef LAUNCH
+#undef LAUNCH_H
     VLLM_CHECK_LAUNCH("gemm256p_kernel");
     return VLLM_OK;
 }

@@ -28,6 +28,7 @@ struct GemmArgs {
     int xP;                 // >0: X is [n, 1+xP, K] and row m reads X row m + m/xP + 1 (CLS rows skipped)
     int variant;            // 0 auto, 1 force 128x128 kernel, 2 force 256x256 8-phase kernel (tuning / tests)
     int variant256;         // 8-phase kernel block rows: 0 auto, 3 -> 192, 4 -> 256
+    int half_tail = 0;      // persistent schedule (launcher): 1 = the tiles of the last, incomplete round run as two half-height tiles each
     int direct_store;       // 8-phase epilogue: 0 through LDS, 1 straight from the accumulator layout, 2 automatic
     // EPI_MSDA only: output features [0, nsplit) come from W / bias and become sampling locations in Y (fp32, ldy),
     // features [nsplit, N) come from W2 / bias2 and become the per-head softmax over L*P == 16 logits in Y2 (fp32, ldy2)
@@ -86,6 +87,9 @@ int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *
                           float offset_scale, float *grad_input, float *grad_offset, float *grad_mask, hipStream_t st);
 int dcnv3_bwd_tiled();       // VLLM_DCNV3_BWD_TILED / vllm_set_option("dcnv3_bwd_tiled")
 int dcnv3_bwd_tiled_set(int v);
+int gemm_half_tail();        // VLLM_GEMM_HALF_TAIL / vllm_set_option("gemm_half_tail"): half-height tiles in the persistent GEMM's last round
+int gemm_half_tail_set(int v);
+long gemm256p_half_launches();
 int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 
