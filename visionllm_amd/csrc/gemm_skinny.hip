@@ -359,7 +359,7 @@ bool gemm_skinny_takes(int epi, const GemmArgs &a)
 {
     if (!gemm_skinny_enabled() || a.K != SK_K || a.M < 4096 || a.xP != 0 || a.ln_in || a.ln_out) return false;
     if (a.ldx < SK_K || (long)a.M * a.ldx * 2 >= (1L << 31) || (long)a.M * a.ldy * 4 >= (1L << 31)) return false;
-    if (epi == EPI_BIAS) return a.N == 256 && a.ldy >= 256;
+    if (epi == EPI_BIAS) return a.N == 256 && a.ldy >= 256 && a.ldy % 8 == 0 && aligned16(a.Y);   // (16-byte output stores)
     if (epi == EPI_F32)   // (the mask travels as dwords: M % 4 == 0 keeps the last one inside the array)
         return a.N == 256 && a.ldy >= 256 && (!a.res || (a.M % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 3u) == 0));
     if (epi == EPI_MSDA)   // 8 heads x L <= 4 levels x 4 points: N = 8 (8 L + 4 L)
