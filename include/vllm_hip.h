@@ -72,6 +72,9 @@ int vllm_device_info(char *name, int cap);
  * "gemm_half_tail" (round 4; VLLM_GEMM_HALF_TAIL): 1 (default) the persistent 8-phase GEMM runs the tiles of its last, incomplete round
  * as two half-height tiles each when they then still fit the grid (qkv at 40 ViT-L tiles: 4.27 rounds of work in 5 -> 4 + a half-tile
  * round); 0 whole tiles.  The same bits either way.
+ * "msda_layer_value_bf16" (round 4; VLLM_MSDA_LAYER_VALUE_BF16): 1 (default) vllm_msda_layer_forward stores the projected value in
+ * bf16 when the query set is not the value pyramid (decoder cross-attention: the gather kernel reads bf16 natively; the reference's
+ * bf16 module rounds the value to bf16 too) and the streaming value GEMM serves the shape; 0 fp32 value everywhere.
  * Environment variables VLLM_MSDA_TILED / VLLM_GEMM_VARIANT / VLLM_ATTN_VARIANT give the initial values.  Returns the
  * previous value or VLLM_EINVAL for an unknown name / value.  (Measured-slower experiments -- MSDA generations 3 and 5, the
  * 4-wave GEMM, the two-row-group attention kernel -- live under tools/experiments/ and are not part of the library.) */

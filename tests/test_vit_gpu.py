@@ -569,7 +569,7 @@ def test_attention_schedule_variants(variant, D, S):
     (40 * 577, 4096, 1024, 2, False),    # fc1 + quick-GELU: 1456 tiles = 5 rounds + 176: does not fit the grid as half tiles
     (32 * 577, 3072, 1024, 1, True),     # the 32-tile batch, GELU: 876 tiles = 3 rounds + 108
     (5 * 1025 + 3, 3200, 3200, 3, None), # InternViT-6B proj at 5 tiles, ragged M, N not a multiple of 256
-    (256 * 40 + 130, 2048, 128, 0, True),      # two K tiles only (41 x 8 = 328 tiles = 1 round + 72): the half tile's pipeline right behind the cross-tile prefetch
+    (8458, 2048, 128, 0, True),                # two K tiles only (45 panels of 192 rows x 8 = 360 tiles = 1 round + 104): the half tile's pipeline right behind the cross-tile prefetch
 ])
 def test_gemm_half_height_tail_round_is_bit_identical(M, N, K, epi, expect_half):
     """Round 4: the persistent schedule runs the tiles of its last, incomplete round as two half-height tiles each (option

@@ -69,13 +69,13 @@ __device__ __forceinline__ void sk_store16(u32x4_t o, __amdgpu_buffer_rsrc_t rs,
 
 // AUX: the per-row epilogue inputs of a chunk travel WITH the chunk (one more LDS-DMA per wave and chunk, same counted wait) -- a
 // register load inside the chunk loop would have to be waited for with vmcnt, and loads return in order: it would drain the ring.
-//   0 none | 1 EPI_F32: the key-padding mask's 64 bytes (every wave its own copy: 16 lanes x 4 bytes)
+//   0 none | 1 EPI_F32 / EPI_BIAS: the key-padding mask's 64 bytes (every wave its own copy: 16 lanes x 4 bytes)
 //   2 / 3 EPI_MSDA: the chunk's reference points, 64 rows x L x {2, 4} floats = 2 / 4 KiB (waves 0-1 / 0-3 one KiB each, the
 //   others a dummy that reads nothing)
 template <int EPI, int NWC, int AUX>
 __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmArgs a)
 {
-    static_assert((EPI == EPI_F32 && AUX <= 1 && NWC == 2) || (EPI == EPI_BIAS && AUX == 0 && NWC == 2) || (EPI == EPI_MSDA && NWC == 3 && (AUX == 2 || AUX == 3)),
+    static_assert((EPI == EPI_F32 && AUX <= 1 && NWC == 2) || (EPI == EPI_BIAS && AUX <= 1 && NWC == 2) || (EPI == EPI_MSDA && NWC == 3 && (AUX == 2 || AUX == 3)),
                   "skinny GEMM: fp32 (+ mask) / bias / MSDA epilogues");
     constexpr int NL = 4 + (AUX ? 1 : 0);   // VMEM loads per wave and chunk
     constexpr int RD = AUX == 3 ? 4 : 2;    // EPI_MSDA: floats per reference point
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
     // contiguous; wave w fetches KiB w of them while that starts inside the block)
     const int ROWB = mL * RD * 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
-        AUX == 1 ? (void *)a.res : (void *)a.ref, 0,
+        AUX == 1 ? (EPI == EPI_BIAS ? (void *)a.row_mask : (void *)a.res) : (void *)a.ref, 0,
         AUX == 1 ? a.M : AUX ? (int)((unsigned)a.M * (unsigned)ROWB) : 0, 0x00020000);
     const unsigned avo = AUX == 1 ? (lane < 16 ? (unsigned)lane * 4u : 0x80000000u)
                                   : (wave * 1024 < SK_R * ROWB ? (unsigned)(wave * 1024 + lane * 16) : 0x80000000u);
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void gemm_skinny_kernel(const GemmAr
                 const unsigned so = (unsigned)(m0 + j * 16) * (unsigned)a.ldy * 2u;
                 unsigned p0x = pack_bf16x2(acc[0][j][0] + bia[0][0], acc[0][j][1] + bia[0][1]), p0y = pack_bf16x2(acc[0][j][2] + bia[0][2], acc[0][j][3] + bia[0][3]);
                 unsigned p1x = pack_bf16x2(acc[1][j][0] + bia[1][0], acc[1][j][1] + bia[1][1]), p1y = pack_bf16x2(acc[1][j][2] + bia[1][2], acc[1][j][3] + bia[1][3]);
+                if (AUX == 1 && dead[j]) { p0x = 0u; p0y = 0u; p1x = 0u; p1y = 0u; }   // key-padding mask: the row is stored as zeros (row fr in every lane row)
                 asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(p0x), "+v"(p1x));
                 asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(p0y), "+v"(p1y));
                 const u32x4_t o = {p0x, p0y, p1x, p1y};
@@ -359,7 +360,9 @@ bool gemm_skinny_takes(int epi, const GemmArgs &a)
 {
     if (!gemm_skinny_enabled() || a.K != SK_K || a.M < 4096 || a.xP != 0 || a.ln_in || a.ln_out) return false;
     if (a.ldx < SK_K || (long)a.M * a.ldx * 2 >= (1L << 31) || (long)a.M * a.ldy * 4 >= (1L << 31)) return false;
-    if (epi == EPI_BIAS) return a.N == 256 && a.ldy >= 256 && a.ldy % 8 == 0 && aligned16(a.Y);   // (16-byte output stores)
+    if (epi == EPI_BIAS)   // (16-byte output stores; a row mask travels as dwords like EPI_F32's)
+        return a.N == 256 && a.ldy >= 256 && a.ldy % 8 == 0 && aligned16(a.Y) &&
+               (!a.row_mask || (a.M % 4 == 0 && (reinterpret_cast<uintptr_t>(a.row_mask) & 3u) == 0));
     if (epi == EPI_F32)   // (the mask travels as dwords: M % 4 == 0 keeps the last one inside the array)
         return a.N == 256 && a.ldy >= 256 && (!a.res || (a.M % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 3u) == 0));
     if (epi == EPI_MSDA)   // 8 heads x L <= 4 levels x 4 points: N = 8 (8 L + 4 L)
@@ -377,7 +380,7 @@ int gemm_skinny_launch(int epi, const GemmArgs &a, hipStream_t st)
     static unsigned long long attr_mask = 0;
     if (first_use_on_device(&attr_mask)) {
 #define SK_ATTR(...) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS)
-        SK_ATTR(EPI_F32, 2, 0); SK_ATTR(EPI_F32, 2, 1); SK_ATTR(EPI_BIAS, 2, 0); SK_ATTR(EPI_MSDA, 3, 2); SK_ATTR(EPI_MSDA, 3, 3);
+        SK_ATTR(EPI_F32, 2, 0); SK_ATTR(EPI_F32, 2, 1); SK_ATTR(EPI_BIAS, 2, 0); SK_ATTR(EPI_BIAS, 2, 1); SK_ATTR(EPI_MSDA, 3, 2); SK_ATTR(EPI_MSDA, 3, 3);
 #undef SK_ATTR
     }
     switch (epi) {
@@ -385,7 +388,10 @@ int gemm_skinny_launch(int epi, const GemmArgs &a, hipStream_t st)
         if (a.res) VLLM_LAUNCH((gemm_skinny_kernel<EPI_F32, 2, 1>), grid, block, SK_LDS, st, a);
         else VLLM_LAUNCH((gemm_skinny_kernel<EPI_F32, 2, 0>), grid, block, SK_LDS, st, a);
         break;
-    case EPI_BIAS: VLLM_LAUNCH((gemm_skinny_kernel<EPI_BIAS, 2, 0>), grid, block, SK_LDS, st, a); break;
+    case EPI_BIAS:
+        if (a.row_mask) VLLM_LAUNCH((gemm_skinny_kernel<EPI_BIAS, 2, 1>), grid, block, SK_LDS, st, a);
+        else VLLM_LAUNCH((gemm_skinny_kernel<EPI_BIAS, 2, 0>), grid, block, SK_LDS, st, a);
+        break;
     case EPI_MSDA:
         if (a.ref_dim == 2) VLLM_LAUNCH((gemm_skinny_kernel<EPI_MSDA, 3, 2>), grid, block, SK_LDS, st, a);
         else VLLM_LAUNCH((gemm_skinny_kernel<EPI_MSDA, 3, 3>), grid, block, SK_LDS, st, a);

@@ -37,6 +37,7 @@ struct GemmArgs {
     const float *ref = nullptr;       // [M, mL, ref_dim] reference points
     const int64_t *shapes = nullptr;  // [mL, 2] (H, W)
     int nsplit = 0, ldy2 = 0, mL = 0, mP = 0, ref_dim = 0, four_d = 0;
+    const uint8_t *row_mask = nullptr;   // EPI_BIAS on the streaming kernel (gemm_skinny.hip; msda_layer.hip's bf16 value): rows with a non-zero byte are stored as zeros
     int res_init = 0;       // EPI_RESIDUAL without LayerScale, 8-phase kernel: the residual is the accumulators' initial value (launcher)
     int prof = 0;           // VLLM_GEMM_PROF=1: the 8-phase kernel adds prologue / main loop / epilogue ticks to device counters
     // Stream-K tail of the 8-phase kernel (gemm256.hip): scratch for fp32 partial tiles + one flag per scratch slot, provided by
@@ -90,6 +91,7 @@ int dcnv3_bwd_tiled_set(int v);
 int gemm_half_tail();        // VLLM_GEMM_HALF_TAIL / vllm_set_option("gemm_half_tail"): half-height tiles in the persistent GEMM's last round
 int gemm_half_tail_set(int v);
 long gemm256p_half_launches();
+int msda_layer_value_bf16_set(int v);   // VLLM_MSDA_LAYER_VALUE_BF16 / vllm_set_option("msda_layer_value_bf16")
 int msda_layer_fused();        // VLLM_MSDA_LAYER_FUSED / vllm_set_option("msda_layer_fused")
 int msda_tiled_enabled();      // VLLM_MSDA_TILED / vllm_set_option("msda_tiled")
 

@@ -14,6 +14,7 @@
 // gemm_epilogue.hpp) does the softmax and the location arithmetic on the accumulator, and the LDS-tiled operator writes
 // bf16 itself.  The layer is then 4 launches: value GEMM, query GEMM, operator, output GEMM.
 #include "common.hpp"
+#include <stdlib.h>
 #include "kernels.hpp"
 #include "msda_sample.hpp"
 
@@ -120,6 +121,13 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 // msda_layer_fused = 0 (option / VLLM_MSDA_LAYER_FUSED): the round-1 composition (two query GEMMs + prep kernel + fp32
 // operator + conversion pass), kept as the A/B reference of the fused epilogue.
 inline bool layer_unfused() { return msda_layer_fused() == 0; }
+// VLLM_MSDA_LAYER_VALUE_BF16=0: keep the value in fp32 for every query set (A/B)
+static int g_layer_value_bf16 = -1;
+inline bool msda_layer_value_bf16()
+{
+    if (g_layer_value_bf16 < 0) { const char *e = getenv("VLLM_MSDA_LAYER_VALUE_BF16"); g_layer_value_bf16 = e && e[0] == '0' ? 0 : 1; }
+    return g_layer_value_bf16 != 0;
+}
 
 inline long align256(long x) { return (x + 255) & ~255L; }
 
@@ -174,6 +182,7 @@ int cvt_launch(const float *src, uint16_t *dst, long n, hipStream_t st, const in
 }
 
 }  // namespace
+int msda_layer_value_bf16_set(int v) { const int old = msda_layer_value_bf16() ? 1 : 0; g_layer_value_bf16 = v != 0; return old; }
 }  // namespace vllm
 
 using namespace vllm;
@@ -242,7 +251,21 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     float *opout = (float *)(ws + w.opout);
     uint16_t *opb = (uint16_t *)(ws + w.opout_bf16);
     prof_mark(PT_MSDA_LAYER, st);
-    // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D]
+    // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D] where the LDS-tiled
+    // operator can run (its windows are fp32: a bf16 value would cost its gather conversions it has no issue slots for).
+    // A query set that is NOT the value pyramid (decoder cross-attention: Lq != S) runs the gather kernel whatever the value's
+    // dtype, and that one reads bf16 natively: the value is then stored in bf16 -- what the reference's own bf16 module computes
+    // (...mask_dn.py:764-766 rounds it to bf16 before the upcast) at half the value GEMM's write and half the operator's read.
+    uint16_t *value16 = (uint16_t *)value;
+    GemmArgs va;
+    {
+        va.X = input_flatten; va.W = d->value_proj_w; va.Y = value16; va.bias = d->value_proj_b; va.scale = nullptr; va.res = nullptr;
+        va.M = B * S; va.N = C; va.K = C; va.ldx = C; va.ldw = C; va.ldy = C; va.ldr = 0; va.P = 0; va.mt = va.nt = 0; va.xP = 0;
+        va.variant = 0; va.variant256 = 0; va.direct_store = 0; va.row_mask = padding_mask;
+    }
+    const bool v16 = Lq != S && msda_layer_value_bf16() && gemm_skinny_takes(EPI_BIAS, va);
+    if (v16) TRY(gemm_bf16_launch(EPI_BIAS, va, st));
+    else
     TRY(gemm(st, EPI_F32, input_flatten, C, d->value_proj_w, C, d->value_proj_b, (uint16_t *)value, C, B * S, C, C, nullptr,
              (const uint16_t *)padding_mask));
     // offsets and logits of the queries (:110-111) in one GEMM; softmax + location arithmetic (:112-129) in its epilogue: the tile
@@ -270,11 +293,12 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     }
     // the operator (:131-139), fp32 arithmetic; bf16 result straight from the LDS-tiled kernel where that one runs
     int where = 0;
-    if (layer_unfused()) TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
+    if (v16) TRY(vllm_msda_forward_bf16(value16, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opb, stream));   // (bf16 result: output_proj's operand)
+    else if (layer_unfused()) TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
     else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st, d->geometry));
     // output_proj (:144).  The conversion pass runs unless the host KNOWS the operator wrote bf16 (pyramid hint); with an
     // unknown geometry it is enqueued and tests the device-side predicate itself.
-    if (!(where && (d->geometry == VLLM_GEO_PYRAMID || d->geometry == VLLM_GEO_NESTED)))
+    if (!v16 && !(where && (d->geometry == VLLM_GEO_PYRAMID || d->geometry == VLLM_GEO_NESTED)))
         TRY(cvt_launch(opout, opb, (long)B * Lq * C, st, where ? shapes : nullptr, L, Lq));
     TRY(gemm(st, EPI_BIAS, opb, C, d->output_proj_w, C, d->output_proj_b, out, C, B * Lq, C, C));
     prof_mark(PT_END, st);

@@ -95,6 +95,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!strcmp(name, "dcnv3_tiled")) { const int old = vllm::dcnv3_tiled_enabled(); vllm::g_dcnv3_tiled = (value < 0 || value > 4) ? 1 : value; return old; }
     if (!strcmp(name, "dcnv3_bwd_tiled")) return vllm::dcnv3_bwd_tiled_set(value);
     if (!strcmp(name, "gemm_half_tail")) return vllm::gemm_half_tail_set(value);
+    if (!strcmp(name, "msda_layer_value_bf16")) return vllm::msda_layer_value_bf16_set(value);
     if (!strcmp(name, "gemm_skinny")) return vllm::gemm_skinny_set(value);
     if (!strcmp(name, "msda_layer_fused")) { const int old = vllm::msda_layer_fused(); vllm::g_layer_fused = value != 0; return old; }
     if (!strcmp(name, "gemm_direct_store")) { const int old = vllm::gemm_direct_store(); vllm::g_gemm_direct = (value < 0 || value > 2) ? 2 : value; return old; }
