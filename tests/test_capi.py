@@ -266,3 +266,15 @@ def test_attention_lane_swaps_read_both_results(tmp_path):
                     break
             assert verdict == "read", f"{name}: second result of the swap at instruction {i} ({ln.strip()}) is {verdict}"
         assert swaps > 0, name
+
+
+def test_every_runtime_option_is_documented_in_the_header():
+    """vllm_set_option's names (csrc/runtime.cpp) are part of the boundary: each must be described in include/vllm_hip.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "visionllm_amd", "csrc", "runtime.cpp")).read()
+    hdr = open(os.path.join(root, "include", "vllm_hip.h")).read()
+    names = sorted(set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', src)))
+    assert len(names) >= 8, names
+    missing = [n for n in names if f'"{n}"' not in hdr]
+    assert not missing, f"options without a description in include/vllm_hip.h: {missing}"
