@@ -27,6 +27,9 @@
 
 // Timing-only ablation builds: -DT9_ABL=<mask>.  1: no multiply-adds in the gather, 2: no LDS reads in the gather,
 // 4: no window DMA, 8: no output stores, 16: no gather at all, 32: no point arithmetic (P1 skipped).
+#ifndef T9_EARLY      // levels of pass 0 a team gathers at the END of its preparing half (behind a meeting point of its own), 0: none
+#define T9_EARLY 0
+#endif
 #ifndef T9_ABL
 #define T9_ABL 0
 #endif
@@ -233,12 +236,13 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     unsigned okm[NP] = {};
     int4 bx = {0, 0, 0, 0};
     int lay = 0;
+    float acc_e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // T9_EARLY: pass 0's sums of the levels gathered before the swap
 
     // Gather of one pass of the 16 (query, head) slots of this wave: the levels whose layout word says `want` (1: staged with the
     // item, 5: the item's late level), software-pipelined two points deep; want == 1 also takes the levels that come from global
     // memory.  A lane holds the point data of ITS level (k); lane LQ of a quad broadcasts them to the quad by DPP.
     auto gather = [&](const float (&w1c)[4], const float (&w2c)[4], const float (&w3c)[4], const float (&w4c)[4], const int (&oc)[4],
-                      float (&acc)[8], int want) {
+                      float (&acc)[8], int want, int lmin, int lmax) {
         const float *vbc = value + ((size_t)cb * S * M + cm) * D;
         const int ln = lane_now();
         const int cA = chunk_of(ln), cA0 = cA + (int)lds_addr(smem);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         int pit[4];
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            act[l] = ((__builtin_amdgcn_readlane(lay, l) >> 24) & 5) == want;
+            act[l] = ((__builtin_amdgcn_readlane(lay, l) >> 24) & 5) == want && l >= lmin && l < lmax;
             pit[l] = ((-__builtin_amdgcn_readlane(bx.w, l) + 1) - __builtin_amdgcn_readlane(bx.z, l) + 1) * 128;
         }
         T9Set sa, sb;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
 #undef T9_RD
         acc[0] = ac.t0.x; acc[1] = ac.t0.y; acc[2] = ac.t1.x; acc[3] = ac.t1.y; acc[4] = ac.u0.x; acc[5] = ac.u0.y; acc[6] = ac.u1.x; acc[7] = ac.u1.y;
         // cold levels: from global memory, the owner lane's point data by ds_bpermute (run-time level)
-        for (int l = 0; l < (want == 1 ? L : 0); ++l) {
+        for (int l = 0; l < (want == 1 && lmax == 4 ? L : 0); ++l) {
             const int lay_l = __builtin_amdgcn_readlane(lay, l);
             if (!((lay_l >> 25) & 1)) continue;
             const int Hc = EXACT ? H0 >> l : uni(s_dim[l]), Wc = EXACT ? W0 >> l : uni(s_dim[4 + l]);
@@ -558,6 +562,20 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 T9_TICK(3)   // DMA issue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
                 T9_TICK(4)   // DMA wait
+                if (T9_EARLY > 0) {
+                    // The preparing half is the shorter one: the team starts on ITS OWN gather as soon as its windows are in -- a second
+                    // meeting point of the team (every wave's share of the windows has landed), no block barrier -- with the first
+                    // T9_EARLY levels of pass 0 (staged ones; a late level and anything from global memory wait for the swap).  The
+                    // eight partial sums travel across the swap barrier into pass 0.
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(s_cnt + 4 + team, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    meet(s_cnt + 4 + team, epoch * TW);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc_e[c] = 0.f;
+                    gather(w1[0], w2[0], w3[0], w4[0], o[0], acc_e, 1, 0, T9_EARLY);
+                    T9_TICK(11)   // early gather
+                }
             }
         }
         // (a compiler-VISIBLE wait: the waits above are inline assembly, and on the path "locations requested, P1 skipped" -- which
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 for (int p = 0; p < NP; ++p) {
                     float acc[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+                    for (int c = 0; c < 8; ++c) acc[c] = (T9_EARLY > 0 && p == 0) ? acc_e[c] : 0.f;
                     // (the late form is a second trip through the same code)
 #pragma unroll 1
                     for (int lt = 0; lt < (has_late ? 2 : 1); ++lt) {
@@ -600,7 +618,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                             if (PROF) pacc[13] += 1;
                             T9_TICK(9)   // late level: meeting point
                         }
-                        gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, lt ? 5 : 1);
+                        gather(w1[0], w2[0], w3[0], w4[0], o[0], acc, lt ? 5 : 1, (T9_EARLY > 0 && p == 0 && lt == 0) ? T9_EARLY : 0, 4);
                     }
                     store_out(acc, qokc[0], prc[0]);
 #define T9_TAKE(P_) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { w1[0][i] = w1[P_][i]; w2[0][i] = w2[P_][i]; w3[0][i] = w3[P_][i]; w4[0][i] = w4[P_][i]; o[0][i] = o[P_][i]; } qokc[0] = qokc[P_]; prc[0] = prc[P_]; }
