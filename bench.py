@@ -281,10 +281,10 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         ab = msda_bytes(t)
         geo = A.known_geometry(t["shapes"], t["loc"].shape[1])
         if tag == "enc":
-            kern = {A.GEO_PYRAMID: "msda_fwd_tiled8_kernel<12 waves in two teams, 1 block per CU> (pyramid items; ONE launch: geometry known on the host)",
-                    A.GEO_NESTED: "msda_fwd_tiled8_kernel<nested maps> (pyramid items; one launch)",
+            kern = {A.GEO_PYRAMID: "msda_fwd_tiled9_kernel<12 waves in two teams, 1 block per CU> (pyramid items; ONE launch: geometry known on the host)",
+                    A.GEO_NESTED: "msda_fwd_tiled9_kernel<nested maps> (pyramid items; one launch)",
                     A.GEO_GENERAL: "msda_fwd_tiled4_kernel (any-geometry LDS-tiled kernel; one launch)",
-                    A.GEO_UNKNOWN: "msda_fwd_tiled8_kernel + empty msda_fwd_tiled4_kernel launch (geometry decided on the device)"}[geo]
+                    A.GEO_UNKNOWN: "msda_fwd_tiled9_kernel + empty msda_fwd_tiled4_kernel launch (geometry decided on the device)"}[geo]
             kern += " fp32, D32, encoder shape Lq=S=37485, B=8"
             out[nm] = entry(ptag, kern, "hbm", ab, sec, n_launch, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab)
         else:
@@ -299,7 +299,7 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
             call(); torch.cuda.synchronize()
             sec = event_time(call, 5)
             out["msda_layer"] = entry("msda_layer", "vllm_msda_layer_forward (bf16 MSDeformAttn module, encoder shape Lq=S=37485, B=8: gemm_skinny_kernel value GEMM "
-                                      "fp32 -> gemm_skinny_kernel query GEMM with softmax + location epilogue -> msda_fwd_tiled8_kernel writing bf16 -> "
+                                      "fp32 -> gemm_skinny_kernel query GEMM with softmax + location epilogue -> msda_fwd_tiled9_kernel writing bf16 -> "
                                       "gemm_skinny_kernel output GEMM)", "hbm", ab, sec, 1, HBM_PEAK_GBS,
                                       "GB/s", 1e9, algorithmic_bytes=ab,
                                       note="the layer every det-head call site runs around the operator; ONE call per instrumented step, behind the 12 "
@@ -320,7 +320,7 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         tn["values"] = [tn["value"]]
         ab = msda_bytes(tn)
         geo_n = A.known_geometry(tn["shapes"], tn["loc"].shape[1])
-        kern_n = ("msda_fwd_tiled8_kernel (pyramid items on NESTED maps: ceil-divided levels" if geo_n in (A.GEO_PYRAMID, A.GEO_NESTED)
+        kern_n = ("msda_fwd_tiled9_kernel (pyramid items on NESTED maps: ceil-divided levels" if geo_n in (A.GEO_PYRAMID, A.GEO_NESTED)
                   else "msda_fwd_tiled4_kernel (any-geometry kernel: levels")
         out["msda_nonpyramid"] = entry("-", kern_n + " 100x167 / 50x84 / 25x42 / 13x21, B=8, Lq=S)", "hbm",
                                        ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,

@@ -41,13 +41,14 @@ const char *vllm_last_error(void);
 /* Fills name[0..cap) with the device's gcnArchName; returns CU count or negative error. */
 int vllm_device_info(char *name, int cap);
 /* Tuning / test knobs (process-wide).  "msda_tiled": encoder-shaped (Lq == S) MSDA forward kernel, same results to fp32
- * rounding: 0 plain gather kernel; 1 automatic (default): generation 8 (msda_tiled8.hip: pyramid items, two teams of waves half a period apart;
- * round 2: generation 7, one software pipeline
- * across items) when the level maps form an exact 2x pyramid -- decided on the device, no host sync -- else generation 4;
+ * rounding: 0 plain gather kernel; 1 automatic (default): generation 9 since the end of round 4 (msda_tiled9.hip: pyramid items, two
+ * teams of waves half a period apart, software-pipelined gather; round 3: generation 8, round 2: generation 7)
+ * when the level maps are nested halves -- decided on the device, no host sync -- else generation 4;
  * 2 generation 4 with 8 waves per block; 3 generation 2; 5 generation 4 with the phase clock (vllm_debug_counters);
  * 8 generation 4, 560-pixel windows, 2 blocks per CU; 9 generation 4, 360 pixels, 3 blocks per CU (the round-1 default);
  * 10-14 generation 6 (msda_tiled6.hip; 10 / 14 with phase clock, 11-13 gather / staging variants); 17 generation 6; 18 generation 8
- * (msda_tiled8.hip, what "automatic" runs on nested level maps since round 3), 19 generation 8 with the phase clock.  15 / 16
+ * (msda_tiled8.hip, what "automatic" ran in round 3), 19 generation 8 with the phase clock, 20 generation 9 (= automatic), 21 generation 9
+ * with the phase clock.  15 / 16
  * (generation 7) are rejected since round 4: that kernel is tools/experiments/msda_tiled7.hip.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
  * kernel, 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the 8-phase kernel's epilogue goes 0 through LDS
  * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).

@@ -16,9 +16,9 @@ import sys
 # kernel-name fragments -> bench.py roofline keys ("gemm" = MLP fc1: the quick_gelu (ViT-L) / gelu (InternViT) epilogue instance)
 # (fc1 runs on the persistent schedule, gemm256p_kernel<EPI, MT, folded-norm consumer, statistics>; the one-workgroup-per-tile
 #  names are kept for A/B passes with VLLM_GEMM_PERSIST=0)
-KEYS = {"vitl": {"msda_fwd_tiled7": "msda", "msda_fwd_tiled8_kernel<1200, false, true>": "msda", "attn_fwd_kernel": "attn", "gemm256p_kernel<2,": "gemm",
+KEYS = {"vitl": {"msda_fwd_tiled7": "msda", "msda_fwd_tiled8_kernel<1200, false, true>": "msda", "msda_fwd_tiled9_kernel<1200, false, true>": "msda", "attn_fwd_kernel": "attn", "gemm256p_kernel<2,": "gemm",
                  "gemm256p_kernelILi2": "gemm", "gemm256_bf16_kernel<2,": "gemm", "gemm256_bf16_kernelILi2": "gemm"},
-        "internvit6b": {"msda_fwd_tiled7": "msda", "msda_fwd_tiled8_kernel<1200, false, true>": "msda", "attn_fwd_kernel": "attn", "gemm256p_kernel<1,": "gemm",
+        "internvit6b": {"msda_fwd_tiled7": "msda", "msda_fwd_tiled8_kernel<1200, false, true>": "msda", "msda_fwd_tiled9_kernel<1200, false, true>": "msda", "attn_fwd_kernel": "attn", "gemm256p_kernel<1,": "gemm",
                         "gemm256p_kernelILi1": "gemm", "gemm256_bf16_kernel<1,": "gemm", "gemm256_bf16_kernelILi1": "gemm"}}
 
 

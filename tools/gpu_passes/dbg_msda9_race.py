@@ -8,7 +8,7 @@ from test_msda_gpu import PYRAMIDS
 from visionllm_amd import _lib, ms_deform_attn as A
 import ctypes
 dev = "cuda:0"
-SIDE = os.environ.get("MSDA9_LIB")     # a side build of tools/experiments/msda_tiled9.hip (tools/msda9_variants.sh) instead of a library mode
+SIDE = os.environ.get("MSDA9_LIB")     # a side build of visionllm_amd/csrc/msda_tiled9.hip (tools/msda9_variants.sh) instead of a library mode
 side = None
 if SIDE:
     side = ctypes.CDLL(SIDE)

@@ -14,7 +14,7 @@ def timeit(iters=10):
     for _ in range(iters): run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-modes = {"gen8": 18}   # (generation 7, mode 15, left the library in round 4: tools/experiments/msda_tiled7.hip)
+modes = {"gen8": 18, "gen9": 20}   # (generation 7, mode 15, left the library in round 4: tools/experiments/msda_tiled7.hip)
 _lib.set_option("msda_tiled", 0); ref = run()
 for k, v in modes.items():
     _lib.set_option("msda_tiled", v); o = run(); torch.cuda.synchronize()

@@ -327,6 +327,9 @@ bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda
 int msda_tiled8_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted,
                        int which);   // msda_tiled8.hip
+int msda_tiled9_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
+                       int B, int S, int M, int L, int Lq, float *out, int prof, hipStream_t st, uint16_t *out16, int hinted,
+                       int which);   // msda_tiled9.hip
 int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                        int B, int S, int M, int L, int Lq, float *out, hipStream_t st);
 
@@ -335,8 +338,9 @@ int msda_tiled6_launch(const float *value, const int64_t *shapes, const int64_t 
 // 10-14 generation 6 (10 / 14 phase clock, 11-13 gather / staging variants); (15 / 16, generation 7, left the library in round 4:
 // tools/experiments/msda_tiled7.hip),
 // 17 generation 6, 18 generation 8 (two teams half a period apart; = automatic on nested maps), 19 generation 8 + phase clock.
-// (Generation 9 -- eight waves, two per SIMD, software-pipelined gather: correct, 508 vs 458 us -- is tools/experiments/msda_tiled9.hip.)
-// Automatic (1): generation 8 (msda_tiled8.hip: pyramid items, two teams of six waves half a period apart) does the work when the
+// 20 generation 9 (msda_tiled9.hip: generation 8's two teams with a software-pipelined gather, straight-line halves and an early gather
+// of the preparing team; = automatic since the end of round 4: 439.6 vs 454.7 us), 21 generation 9 + phase clock.
+// Automatic (1): generation 9 (pyramid items, two teams of six waves half a period apart) does the work when the
 // level maps are nested halves -- it checks that on the device, from the shape tensor, and returns at once otherwise -- and the
 // generation-4 launch behind it skips such maps, so exactly one of the two runs whatever the geometry, without a host
 // synchronisation.
@@ -352,14 +356,17 @@ int msda_tiled_launch(const float *value, const int64_t *shapes, const int64_t *
     const bool fits32 = (long)S * M * 32 < (1L << 30) && (long)B * Lq * M * L * P * 2 < (1L << 30);
     // geometry (VLLM_GEO_*): what the HOST knows about the level maps.  UNKNOWN: both kernels are enqueued and the device
     // picks (no host synchronisation; one ~5 us empty launch); PYRAMID / GENERAL: exactly one launch.
-    if ((mode == 1 || mode == 18 || mode == 19) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
+    if ((mode == 1 || mode == 18 || mode == 19 || mode == 20 || mode == 21) && fits32 && msda_tiled6_ok(32, L, P, Lq, S, B, M) && aligned16(loc) && aligned16(attw) &&
         geometry != VLLM_GEO_GENERAL) {
         if (out16 && wrote16) *wrote16 = 1; else out16 = nullptr;
         // host hint: PYRAMID = exact halves, NESTED = halves rounded either way (one launch each); UNKNOWN: the device decides
         const int hinted = geometry == VLLM_GEO_PYRAMID || geometry == VLLM_GEO_NESTED;
         {
             const int which = geometry == VLLM_GEO_PYRAMID ? 1 : geometry == VLLM_GEO_NESTED ? 2 : 3;
-            if (int e = msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 19, st, out16, hinted, which)) return e;
+            const int e = (mode == 18 || mode == 19)
+                              ? msda_tiled8_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 19, st, out16, hinted, which)
+                              : msda_tiled9_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, mode == 21, st, out16, hinted, which);
+            if (e) return e;
         }
         if (hinted) return VLLM_OK;
         return msda_tiled4_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 2, st);

@@ -1,5 +1,9 @@
-// Multi-scale deformable attention forward, LDS-tiled kernel, generation 9 ("msda_tiled" option 20 / 21): generation 8's pyramid
-// items and two teams half a period apart, on EIGHT waves (two per SIMD) with a software-pipelined gather.
+// Multi-scale deformable attention forward, LDS-tiled kernel, generation 9 ("msda_tiled" option 20; the automatic choice since the end
+// of round 4): generation 8's pyramid items and two teams half a period apart with a software-pipelined gather and straight-line
+// halves.  LIBRARY BUILD: twelve waves (teams of six, T9_TW = 6 -- generation 8's occupancy), the gathering wave at s_setprio 1, and the
+// preparing team gathering level 0 of pass 0 of its own item at the end of its half (T9_EARLY = 1): 439.6 us against generation 8's
+// 454.7 on the same box (profiles/r04_msda9_two_per_simd.txt).  The text below describes the EIGHT-wave form the file started as
+// (-DT9_TW=4: 508 us); both build from this file (tools/msda9_variants.sh).
 //
 // What generation 8's clocks showed (profiles/r03_msda8_two_teams.txt): a wave of the gathering team takes ~530 cycles per point --
 // 10 VALU for addresses / weight broadcasts, 8 ds_read_b128, the LDS round trip, 16 v_pk_fma_f32, strictly one after the other --
@@ -28,7 +32,7 @@
 // Timing-only ablation builds: -DT9_ABL=<mask>.  1: no multiply-adds in the gather, 2: no LDS reads in the gather,
 // 4: no window DMA, 8: no output stores, 16: no gather at all, 32: no point arithmetic (P1 skipped).
 #ifndef T9_EARLY      // levels of pass 0 a team gathers at the END of its preparing half (behind a meeting point of its own), 0: none
-#define T9_EARLY 0
+#define T9_EARLY 1
 #endif
 #ifndef T9_ABL
 #define T9_ABL 0
@@ -40,10 +44,10 @@
 #define T9_WAITCNT 8
 #endif
 #ifndef T9_TW         // waves per team: 4 (8 waves, 2 per SIMD, 3 passes of 64 slots) or 6 (12 waves, 3 per SIMD, 2 passes of 96 slots:
-#define T9_TW 4       // generation 8's shape with this file's straight-line halves and pipelined gather)
+#define T9_TW 6       // generation 8's shape with this file's straight-line halves and pipelined gather): the library's build
 #endif
 #ifndef T9_GPRIO      // s_setprio of a wave while it gathers
-#define T9_GPRIO 2
+#define T9_GPRIO 1
 #endif
 
 namespace vllm {

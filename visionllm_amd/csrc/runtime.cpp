@@ -74,7 +74,7 @@ int msda_tiled_enabled()
     if (g_msda_tiled < 0) {
         const char *e = getenv("VLLM_MSDA_TILED");
         g_msda_tiled = e ? atoi(e) : 1;
-        if (g_msda_tiled < 0 || g_msda_tiled > 19 || g_msda_tiled == 4 || g_msda_tiled == 6 || g_msda_tiled == 7 || g_msda_tiled == 15 || g_msda_tiled == 16) g_msda_tiled = 1;
+        if (g_msda_tiled < 0 || g_msda_tiled > 21 || g_msda_tiled == 4 || g_msda_tiled == 6 || g_msda_tiled == 7 || g_msda_tiled == 15 || g_msda_tiled == 16) g_msda_tiled = 1;
     }
     return g_msda_tiled;
 }
@@ -85,8 +85,8 @@ extern "C" int vllm_set_option(const char *name, int value)
     if (!name) return VLLM_EINVAL;
     if (!strcmp(name, "msda_tiled")) {
         const int old = vllm::msda_tiled_enabled();
-        if (value < 0 || value > 19 || value == 4 || value == 6 || value == 7 || value == 15 || value == 16) {
-            vllm::set_error("msda_tiled must be one of 0, 1, 2, 3, 5, 8, 9, 10..14, 17, 18, 19");
+        if (value < 0 || value > 21 || value == 4 || value == 6 || value == 7 || value == 15 || value == 16) {
+            vllm::set_error("msda_tiled must be one of 0, 1, 2, 3, 5, 8, 9, 10..14, 17 .. 21");
             return VLLM_EINVAL;
         }
         vllm::g_msda_tiled = value;
@@ -110,7 +110,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     vllm::set_error("unknown option %s", name);
     return VLLM_EINVAL;
 }
-namespace vllm { int dcnv3_pipe_debug_counters(long *out, int n); int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda8_debug_counters(long *out, int n); }
+namespace vllm { int dcnv3_pipe_debug_counters(long *out, int n); int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda8_debug_counters(long *out, int n); int msda9_debug_counters(long *out, int n); }
 extern "C" int vllm_debug_counters(long *out, int n)
 {
     if (!out || n <= 0) { vllm::set_error("vllm_debug_counters: bad arguments"); return VLLM_EINVAL; }
@@ -118,7 +118,7 @@ extern "C" int vllm_debug_counters(long *out, int n)
     if (vllm::dcnv3_tiled_enabled() == 2) return vllm::dcnv3_pipe_debug_counters(out, n);
     if (vllm::dcnv3_tiled_enabled() == 4) return vllm::dcnv3_debug_counters(out, n);
     const int mode = vllm::msda_tiled_enabled();
-    return mode >= 18 ? vllm::msda8_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
+    return mode >= 20 ? vllm::msda9_debug_counters(out, n) : mode >= 18 ? vllm::msda8_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
 }
 // ---- in-step kernel timing ----------------------------------------------------------------------------------------
 #include <vector>
