@@ -344,6 +344,13 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         del go
     except Exception as e:   # measurement extra: never fail the bench line for it
         out["msda_bwd"] = {"error": repr(e)}
+    # SURVEY 8(f) rows 3 / 4 (round-4 review, item 6): DCNv3 forward at two InternImage stages, region point sampling, visual-token
+    # splice -- none is part of the timed step (the north-star path has no InternImage backbone / region prompts in it); isolated
+    # launches on this box so that every row of 8(f) has a driver-run fraction.  Algorithmic bytes = every operand once.
+    try:
+        out.update(extra_rooflines(dev, entry))
+    except Exception as e:   # measurement extra: never fail the bench line for it
+        out["dcnv3"] = {"error": repr(e)}
     # attention: MFMA bound, flops = 4*H*S^2*d per tile
     qkv = torch.randn(n_tiles, S, 3, H, D, device=dev).to(torch.bfloat16)
     ao = torch.empty(n_tiles, S, H, D, dtype=torch.bfloat16, device=dev)
@@ -406,6 +413,63 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
     return out
 
 
+def extra_rooflines(dev, entry):
+    """rooflines.dcnv3 / dcnv3_84 / point_sample / point_sample_mean / splice (isolated; reference: ops_dcnv3/test.py:19-96 shapes scaled to
+    InternImage stages, region_encoder.py:95-145, modeling_visionllmv2.py:582-605)."""
+    from visionllm_amd import dcnv3 as DC
+    from visionllm_amd import region_encoder as RE
+    from visionllm_amd import splice as SP
+    out = {}
+    torch.manual_seed(0)
+    k = 3
+    for nm, (N, H, W, G, Cg) in (("dcnv3", (8, 168, 168, 20, 32)), ("dcnv3_84", (8, 84, 84, 40, 32))):
+        x = torch.randn(N, H, W, G * Cg, device=dev)
+        off = torch.randn(N, H, W, G * k * k * 2, device=dev)
+        m = torch.softmax(torch.randn(N, H, W, G, k * k, device=dev), -1).reshape(N, H, W, -1)
+        f = lambda: DC.dcnv3_forward(x, off, m, k, k, 1, 1, 1, 1, 1, 1, G, Cg, 1.0)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, 10)
+        ab = (x.numel() * 2 + off.numel() + m.numel()) * 4.0
+        out[nm] = entry("-", f"dcnv3_fwd_pipe_kernel (fp32, N{N} {H}x{W}, {G} groups x {Cg} channels, 3x3 points: an InternImage stage)", "hbm", ab, sec, 0,
+                        HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab, note="not part of the step (SURVEY 8f row 3); input + output + offsets + mask, fp32")
+        del x, off, m
+    # region point sampling: 16 regions x 2304 points on the three ViT feature maps concatenated (region_encoder.py:135: C = 3 x 1024 at 24 x 24)
+    N, C, H, W, P = 16, 3072, 24, 24, 2304
+    x = torch.randn(N, C, H, W, device=dev)
+    pts = torch.rand(N, P, 2, device=dev)
+    valid = torch.rand(N, P, device=dev) < 0.8
+    with torch.no_grad():
+        f = lambda: RE.point_sample(x, pts)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, 10)
+        ab = (x.numel() + pts.numel() + N * C * P) * 4.0
+        out["point_sample"] = entry("-", f"point_sample_kernel (fp32, {N} regions x {P} points, C{C} on {H}x{W})", "hbm", ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9,
+                                    algorithmic_bytes=ab, note="not part of the step (SURVEY 8f row 4); feature map + points read, (N, C, P) written")
+        f = lambda: RE.point_sample_masked_mean(x, pts, valid)  # noqa: E731
+        f(); torch.cuda.synchronize()
+        sec = event_time(f, 10)
+        ab = (x.numel() + pts.numel() + N * C) * 4.0 + valid.numel()
+        out["point_sample_mean"] = entry("-", f"point_sample_mean_kernel (the fused masked mean of region_encoder.py:135-140, same shapes)", "hbm", ab, sec, 0,
+                                         HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
+                                         note="tiny by construction: 113 MB of feature maps, (N, C) out; latency-bound, listed for completeness")
+    del x, pts, valid
+    # visual-token splice: 8 samples x 4096 positions x 4096 channels bf16, 40 tiles x 576 tokens scattered into the <im_patch> slots
+    B, Lt, Cc, T = 8, 4096, 4096, 576
+    emb = torch.randn(B, Lt, Cc, device=dev).to(torch.bfloat16)
+    ids = torch.zeros(B, Lt, dtype=torch.int64, device=dev)
+    ids[:, 100:100 + 5 * T] = 7
+    feats = torch.randn(B * 5, T, Cc, device=dev).to(torch.bfloat16)
+    f = lambda: SP.splice_visual_tokens(emb, ids, 7, feats, split_sizes=[5] * B)  # noqa: E731
+    f(); torch.cuda.synchronize()
+    sec = event_time(f, 10)
+    ab = 2.0 * feats.numel() * 2
+    out["splice"] = entry("-", f"splice_visual_tokens: torch.nonzero + vllm_scatter_rows_bf16 ({B * 5 * T} rows x {Cc} bf16 into [{B}, {Lt}, {Cc}])", "hbm", ab, sec, 0,
+                          HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
+                          note="not part of the step (SURVEY 8 row a12 / 8f row 4); time includes the index bookkeeping in torch (mask, nonzero, has_image gather); "
+                               "bytes = rows read + rows written")
+    return out
+
+
 def _median_time(fn, reps=3, warmup=1):
     """1 warm-up + >= 3 timed repetitions, median."""
     for _ in range(warmup):
@@ -419,6 +483,24 @@ def _median_time(fn, reps=3, warmup=1):
 
 
 def cpu_baseline(ivit=False):
+    """Two legs (round-4 review, item 6): the setting we measured fastest (32 threads) is `value`; the ALL-cores figure BASELINE.md
+    section 2 asks for is reported beside it as `all_cores` (one warm-up + ONE repetition: it is the slower of the two on a 256-thread
+    host and the whole leg has to stay within the bench's few minutes)."""
+    main_leg = _cpu_leg(ivit, min(32, os.cpu_count() or 1), reps=3)
+    n_all = os.cpu_count() or 1
+    if n_all > main_leg["cores"]:
+        try:
+            allc = _cpu_leg(ivit, n_all, reps=1)
+            main_leg["all_cores"] = dict(value=allc["value"], unit=allc["unit"], cores=allc["cores"],
+                                         sample="the same sample with torch.set_num_threads(os.cpu_count()); 1 warm-up + 1 repetition")
+        except Exception as e:   # never fail the bench line for the second leg
+            main_leg["all_cores"] = {"error": repr(e)}
+    else:
+        main_leg["all_cores"] = dict(value=main_leg["value"], unit=main_leg["unit"], cores=main_leg["cores"], sample="same leg: the host has no more threads")
+    return main_leg
+
+
+def _cpu_leg(ivit, threads, reps):
     """The reference's CPU path on the host cores of this box, bounded sample, extrapolated to images/sec.
 
     vitl: transformers.CLIPVisionModel (the class the reference instantiates, modeling_visionllmv2.py:135; eager attention,
@@ -431,9 +513,9 @@ def cpu_baseline(ivit=False):
     from oracle import vit as OV
     # torch's CPU kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box for these
     # single-tile problem sizes: 32 threads (or all, if fewer) is the fastest setting we measured
-    threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
+    _mt = lambda fn: _median_time(fn, reps=reps)  # noqa: E731
     with torch.no_grad():
         if not ivit:
             from transformers import CLIPVisionConfig, CLIPVisionModel
@@ -443,11 +525,11 @@ def cpu_baseline(ivit=False):
 
             def run_vit():
                 hs[0] = model(pixel_values=x, output_hidden_states=True).hidden_states
-            t_vit = _median_time(run_vit)
+            t_vit = _mt(run_vit)
             C = VIT["hidden_size"]
             bsd = {"0.weight": torch.randn(LLM_HIDDEN, C) * 0.02, "0.bias": torch.zeros(LLM_HIDDEN),
                    "2.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "2.bias": torch.zeros(LLM_HIDDEN)}
-            t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "mlp2x_gelu", hs[0][-2][:, 1:]))
+            t_bridge = _mt(lambda: OV.bridge_forward(bsd, "mlp2x_gelu", hs[0][-2][:, 1:]))
             vit_note = (f"transformers {__import__('transformers').__version__} CLIPVisionModel ViT-L/14-336 fp32 eager, the 5 tiles of one "
                         f"image x 24 layers ({t_vit:.2f}s) + mlp2x_gelu bridge on them ({t_bridge:.2f}s)")
         else:
@@ -465,23 +547,23 @@ def cpu_baseline(ivit=False):
                            pfx + "mlp.fc2.bias": torch.zeros(C), pfx + "norm1.weight": torch.ones(C), pfx + "norm2.weight": torch.ones(C),
                            pfx + "ls1": torch.full((C,), 0.1), pfx + "ls2": torch.full((C,), 0.1)})
             x = torch.randn(TILES_PER_IMAGE, 3, 448, 448)   # the 5 tiles of ONE image
-            t2 = _median_time(lambda: OV.intern_vit_forward(sd, cfg, x))
+            t2 = _mt(lambda: OV.intern_vit_forward(sd, cfg, x))
             t_vit = t2 * (IVIT["num_hidden_layers"] / 2)
             bsd = {"0.weight": torch.ones(4 * C), "0.bias": torch.zeros(4 * C), "1.weight": torch.randn(LLM_HIDDEN, 4 * C) * 0.02,
                    "1.bias": torch.zeros(LLM_HIDDEN), "3.weight": torch.randn(LLM_HIDDEN, LLM_HIDDEN) * 0.02, "3.bias": torch.zeros(LLM_HIDDEN)}
             feats = OV.select_features([torch.randn(TILES_PER_IMAGE, S, C)] * 2, -2, True)
-            t_bridge = _median_time(lambda: OV.bridge_forward(bsd, "internvl_mlp", feats))
+            t_bridge = _mt(lambda: OV.bridge_forward(bsd, "internvl_mlp", feats))
             vit_note = (f"InternViT-6B restatement (oracle/vit.py) fp32, the 5 tiles (448^2) of one image x 2 of 48 layers ({t2:.2f}s), "
                         f"EXTRAPOLATED x24 = {t_vit:.1f}s + pixel-shuffle + internvl_mlp bridge on them ({t_bridge:.2f}s)")
         g = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], mode="encoder_like", seed=0)
         tv, tl, tw = torch.from_numpy(g["value"]), torch.from_numpy(g["loc"]), torch.from_numpy(g["attw"])
-        t_msda_enc = _median_time(lambda: OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw))
+        t_msda_enc = _mt(lambda: OM.grid_sample_twin(tv, g["shapes"].tolist(), tl, tw))
         gd = make_inputs(1, MSDA["M"], MSDA["D"], MSDA["shapes"], MSDA["P"], Lq=MSDA["dec_queries"], mode="encoder_like", seed=1)
         dv, dl, dw = torch.from_numpy(gd["value"]), torch.from_numpy(gd["loc"]), torch.from_numpy(gd["attw"])
-        t_msda_dec = _median_time(lambda: OM.grid_sample_twin(dv, gd["shapes"].tolist(), dl, dw))
+        t_msda_dec = _mt(lambda: OM.grid_sample_twin(dv, gd["shapes"].tolist(), dl, dw))
     t_image = t_vit + t_bridge + MSDA["enc_layers"] * t_msda_enc + MSDA["dec_layers"] * t_msda_dec
     return dict(value=1.0 / t_image, unit="images/sec", cores=threads, kind="port",
-                sample=(f"{threads} of the box's {os.cpu_count()} host threads (BASELINE.md section 2 says all: torch's CPU kernels get slower beyond ~32 at these sizes), 1 warm-up + 3 repetitions each, median: {vit_note} + reference grid_sample MSDA twin B=1 "
+                sample=(f"{threads} of the box's {os.cpu_count()} host threads (the all-cores figure BASELINE.md section 2 asks for is in `all_cores`), 1 warm-up + {reps} repetition(s) each, median: {vit_note} + reference grid_sample MSDA twin B=1 "
                         f"Lq=37485 ({t_msda_enc:.2f}s) and Lq=900 ({t_msda_dec:.2f}s); sample = ONE image: its 5 tiles in one batch + 6 encoder-shaped + 6 "
                         f"decoder-shaped MSDA calls at B=1 (one call of each shape timed, x6)"))
 

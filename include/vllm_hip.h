@@ -221,6 +221,11 @@ int vllm_dcnv3_forward_f32(const float *input, const float *offset, const float 
 int vllm_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, int N, int H, int W, int G, int C,
                            int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, double offset_scale, double *out,
                            vllm_stream_t stream);
+/* Half precision (round 5): the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF (dcnv3_cuda.cu:69) with opmath_t = float.
+ * IEEE binary16 tensors as uint16_t bit patterns; fp32 arithmetic, the output rounded to nearest even once. */
+int vllm_dcnv3_forward_f16(const uint16_t *input, const uint16_t *offset, const uint16_t *mask, int N, int H, int W, int G, int C,
+                           int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float offset_scale, uint16_t *out,
+                           vllm_stream_t stream);
 /* Backward (round 4).  Replaces DCNv3.dcnv3_backward (ops_dcnv3/src/dcnv3.h:41-64, cuda/dcnv3_cuda.cu:92-174; kernels
  * dcnv3_im2col_cuda.cuh:86-146, 279-857), called by DCNv3Function.backward (functions/dcnv3_func.py:51-59).
  * grad_output [N, Ho, Wo, G*C]; grad_input [N, H, W, G*C] MUST BE ZERO-FILLED by the caller (the reference's host code allocates it
@@ -232,6 +237,15 @@ int vllm_dcnv3_backward_f32(const float *input, const float *offset, const float
 int vllm_dcnv3_backward_f64(const double *input, const double *offset, const double *mask, const double *grad_output, int N, int H, int W,
                             int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, double offset_scale,
                             double *grad_input, double *grad_offset, double *grad_mask, vllm_stream_t stream);
+
+/* Half-precision backward (round 5; dcnv3_cuda.cu:147 dispatches AND_HALF too): operands and gradients are binary16, the arithmetic
+ * is the fp32 backward on widened copies in the CALLER's workspace (vllm_dcnv3_backward_f16_workspace bytes, 16-byte aligned; -1 for
+ * an invalid geometry), every gradient rounded once.  grad_input need not be zero-filled here (the fp32 accumulator is). */
+long vllm_dcnv3_backward_f16_workspace(int N, int H, int W, int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
+int vllm_dcnv3_backward_f16(const uint16_t *input, const uint16_t *offset, const uint16_t *mask, const uint16_t *grad_output, int N, int H,
+                            int W, int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float offset_scale,
+                            uint16_t *grad_input, uint16_t *grad_offset, uint16_t *grad_mask, void *workspace, long workspace_bytes,
+                            vllm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * f4. Region-encoder point sampling.

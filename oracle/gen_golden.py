@@ -482,6 +482,53 @@ def gen_dcnv3():
     case("bwd_c71", 2, 8, 8, 2, 71, 3, 3, 1, 1, 1, 1, 2.0, 33)
 
 
+def gen_dcnv3_half():
+    """DCNv3 in half precision (round 5; the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF with opmath_t = float,
+    ops_dcnv3/src/cuda/dcnv3_cuda.cu:69, 147: half operands, fp32 arithmetic, the result rounded to half).  F.grid_sample has no CPU
+    half kernel, so the reference's twin runs in fp32 ON THE HALF-ROUNDED OPERANDS and its result / its autograd gradients are rounded
+    to half -- the same quantity up to fp32 rounding before the final rounding.  -> tests/golden/dcnv3_half.npz (three cases)."""
+    glb = {"torch": torch, "F": F}
+    fns = ast_extract(f"{REF}/visionllmv2/model/ops_dcnv3/functions/dcnv3_func.py",
+                      ["_get_reference_points", "_generate_dilation_grids", "dcnv3_core_pytorch"], glb)
+    glb.update(fns)
+    core = fns["dcnv3_core_pytorch"]
+    rec = {}
+    for tag, (N, H, W, M, D, k, stride, pad, dil, scale, seed) in {"c16": (2, 8, 8, 4, 16, 3, 1, 1, 1, 2.0, 41),      # vector path
+                                                                   "c32": (2, 12, 10, 2, 32, 3, 1, 1, 1, 1.0, 42),    # windowed backward
+                                                                   "c5": (1, 7, 10, 3, 5, 3, 2, 1, 1, 0.5, 43)}.items():   # scalar path, stride 2
+        torch.manual_seed(seed)
+        Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        P = k * k
+        inp = torch.randn(N, H, W, M * D).half()
+        offset = (torch.randn(N, Ho, Wo, M * P * 2) * 2.0).half()
+        # keep every sampling location away from integer coordinates: there floor() (the kernels) and grid_sample's own convention may
+        # pick different cells, and grad_offset is discontinuous across a cell border -- half-rounded offsets hit such points exactly
+        c0 = (dil * (k - 1)) >> 1
+        for _ in range(4):
+            o5 = offset.float().reshape(N, Ho, Wo, M, P, 2)
+            pi = torch.arange(k).repeat_interleave(k).float() * dil          # kernel_w outer
+            pj = torch.arange(k).repeat(k).float() * dil                     # kernel_h inner
+            lw = c0 * (1 - scale) + (pi[None, None, None, None, :] + o5[..., 0]) * scale
+            lh = c0 * (1 - scale) + (pj[None, None, None, None, :] + o5[..., 1]) * scale
+            near = torch.stack([(lw - lw.round()).abs() < 0.03, (lh - lh.round()).abs() < 0.03], -1)
+            if not bool(near.any()):
+                break
+            offset = (o5 + near.float() * 0.13).reshape(N, Ho, Wo, M * P * 2).half()
+        mask = torch.rand(N, Ho, Wo, M, P) + 1e-5
+        mask = (mask / mask.sum(-1, keepdim=True)).reshape(N, Ho, Wo, M * P).half()
+        grad_out = torch.randn(N, Ho, Wo, M * D).half()
+        a, b, c = (t.float().requires_grad_(True) for t in (inp, offset, mask))
+        out = core(a, b, c, k, k, stride, stride, pad, pad, dil, dil, M, D, scale)
+        out.backward(grad_out.float())
+        rec.update({f"{tag}.input": inp.numpy(), f"{tag}.offset": offset.numpy(), f"{tag}.mask": mask.numpy(), f"{tag}.grad_out": grad_out.numpy(),
+                    f"{tag}.out": out.detach().half().numpy(), f"{tag}.grad_input": a.grad.half().numpy(), f"{tag}.grad_offset": b.grad.half().numpy(),
+                    f"{tag}.grad_mask": c.grad.half().numpy(), f"{tag}.out_f32": out.detach().numpy(),
+                    f"{tag}.params": np.array([k, k, stride, stride, pad, pad, dil, dil, M, D], dtype=np.int64), f"{tag}.offset_scale": np.array(scale)})
+        print(f"dcnv3_half {tag}: out {tuple(out.shape)} |out| max {float(out.abs().max()):.3g} |grad_offset| max {float(b.grad.abs().max()):.3g}")
+    np.savez_compressed(os.path.join(OUT, "dcnv3_half.npz"), torch_version=np.array(torch.__version__), **rec)
+
+
 def gen_point_sample():
     """Region-encoder point sampling: the reference's own ``point_sample`` (region_encoder.py:24-47) and the masked-mean
     pooling lines (:135-140) on seeded inputs, incl. points on / beyond the border and a region without points."""
@@ -658,6 +705,7 @@ if __name__ == "__main__":
     gen_token_loops()
     gen_region_branch()
     gen_dcnv3()
+    gen_dcnv3_half()
     gen_point_sample()
     gen_intern_vit()
     gen_clip()

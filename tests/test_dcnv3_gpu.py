@@ -262,3 +262,41 @@ def test_backward_argument_checks():
         A.dcnv3_backward(x, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 2, 4, 1.0, go[:, :3].contiguous())
     gi, gof, gm = A.dcnv3_backward(x, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 2, 4, 1.0, go)
     assert gi.shape == x.shape and gof.shape == off.shape and gm.shape == msk.shape and float(gi.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["c16", "c32", "c5"])
+def test_half_precision_forward_and_backward(tag):
+    """Round 5: float16 operands (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF with opmath_t = float,
+    ops_dcnv3/src/cuda/dcnv3_cuda.cu:69, 147).  Three checks: (1) against the fixture made from the reference's twin on the widened
+    operands (tests/golden/dcnv3_half.npz, one half ulp: both sides round an fp32 result); (2) BIT-EXACT against this library's own
+    fp32 kernels on the widened operands rounded to half -- the half entry points add nothing but the conversions; (3) autograd through
+    DCNv3Function in half."""
+    g = load_golden("dcnv3_half.npz")
+    kh, kw, sh, sw, ph, pw, dh, dw, M, Dc = [int(v) for v in g[f"{tag}.params"]]
+    a = (kh, kw, sh, sw, ph, pw, dh, dw, M, Dc, float(g[f"{tag}.offset_scale"]))
+    h = lambda k: torch.from_numpy(g[f"{tag}.{k}"]).to(DEV)
+    inp, off, msk, go = h("input"), h("offset"), h("mask"), h("grad_out")
+    assert inp.dtype == torch.float16
+    out = A.dcnv3_forward(inp, off, msk, *a)
+    assert out.dtype == torch.float16
+    np.testing.assert_allclose(out.float().cpu().numpy(), g[f"{tag}.out"].astype(np.float32), rtol=1e-3, atol=1e-3)
+    from visionllm_amd import _lib
+    old = _lib.set_option("dcnv3_tiled", 0)     # the gather kernel: the half kernel is its instantiation
+    try:
+        out32 = A.dcnv3_forward(inp.float(), off.float(), msk.float(), *a)
+    finally:
+        _lib.set_option("dcnv3_tiled", old)
+    assert torch.equal(out, out32.half())
+    gi, gof, gm = A.dcnv3_backward(inp, off, msk, *a, go)
+    for ours, key in ((gi, "grad_input"), (gof, "grad_offset"), (gm, "grad_mask")):
+        ref = g[f"{tag}.{key}"].astype(np.float32)
+        assert ours.dtype == torch.float16
+        np.testing.assert_allclose(ours.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * max(np.abs(ref).max(), 1e-3), err_msg=key)
+    gi32, gof32, gm32 = A.dcnv3_backward(inp.float(), off.float(), msk.float(), *a, go.float())
+    assert torch.equal(gof, gof32.half()) and torch.equal(gm, gm32.half())
+    torch.testing.assert_close(gi.float(), gi32, rtol=1e-3, atol=1e-3 * float(gi32.abs().max()))    # (atomics: the fp32 sums differ in the last bits run to run)
+    x = inp.clone().requires_grad_(True)
+    o2 = A.DCNv3Function.apply(x, off, msk, *a, 256)
+    o2.backward(go)
+    assert torch.equal(o2.detach(), out) and x.grad.dtype == torch.float16
+    torch.testing.assert_close(x.grad.float(), gi.float(), rtol=1e-3, atol=1e-3 * float(gi32.abs().max()))

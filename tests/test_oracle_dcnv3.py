@@ -65,3 +65,24 @@ def test_c_oracle_backward_matches_reference_autograd(name):
     for ours, key in ((gi, "grad_input_f64"), (go, "grad_offset_f64"), (gm, "grad_mask_f64")):
         np.testing.assert_allclose(ours, g[key], rtol=1e-2, atol=1e-3, err_msg=key)          # the reference's float thresholds (test.py:203-235)
         np.testing.assert_allclose(ours, g[key], rtol=2e-3, atol=2e-5 * np.abs(g[key]).max(), err_msg=key)
+
+
+HALF_TAGS = ["c16", "c32", "c5"]
+
+
+@pytest.mark.parametrize("tag", HALF_TAGS)
+def test_c_oracle_on_half_operands_matches_reference_twin(tag):
+    """Round 5 (half precision, dcnv3_cuda.cu:69 / :147 dispatch AND_HALF with fp32 arithmetic): the fp32 C restatement on the WIDENED
+    half operands, rounded to half, against the fixture made by the reference's twin the same way (gen_golden.py::gen_dcnv3_half).
+    Both round an fp32 result once: they may differ by one half ulp where the fp32 values straddle a rounding boundary."""
+    g = load_golden("dcnv3_half.npz")
+    kh, kw, sh, sw, ph, pw, dh, dw, M, Dc = [int(v) for v in g[f"{tag}.params"]]
+    a = (kh, kw, sh, sw, ph, pw, dh, dw, M, Dc, float(g[f"{tag}.offset_scale"]))
+    w = lambda k: g[f"{tag}.{k}"].astype(np.float32)
+    out = D.forward(w("input"), w("offset"), w("mask"), *a)
+    np.testing.assert_allclose(out, g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out.astype(np.float16).astype(np.float32), w("out"), rtol=1e-3, atol=1e-3)
+    gi, go, gm = D.backward(w("input"), w("offset"), w("mask"), w("grad_out"), *a)
+    for ours, key in ((gi, "grad_input"), (go, "grad_offset"), (gm, "grad_mask")):
+        ref = w(key)
+        np.testing.assert_allclose(ours.astype(np.float16).astype(np.float32), ref, rtol=2e-3, atol=2e-3 * max(np.abs(ref).max(), 1e-3), err_msg=key)

@@ -22,15 +22,19 @@ int dcnv3_tiled_enabled();   // runtime.cpp: 0 gather kernel, 1 pipelined tiled 
 
 namespace {
 
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 template <typename T> struct Opmath { typedef T type; };
 template <typename T> __device__ __forceinline__ T floor_t(T x);
 template <> __device__ __forceinline__ float floor_t<float>(float x) { return floorf(x); }
 template <> __device__ __forceinline__ double floor_t<double>(double x) { return floor(x); }
 
 // K3 = true: 3x3 kernel, the 9-point loop is fully unrolled (36 independent corner loads per lane for the scheduler).
-template <typename T, int VEC, bool K3>
-__global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T *__restrict__ in, const T *__restrict__ off,
-                                                        const T *__restrict__ msk, T *__restrict__ out, long total,
+// TIO: storage type of the four tensors (float, double, or -- round 5 -- _Float16: the reference dispatches
+// AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69, with opmath_t = float: half operands, fp32 arithmetic, one rounding of
+// the output); T: the arithmetic type.
+template <typename TIO, typename T, int VEC, bool K3>
+__global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const TIO *__restrict__ in, const TIO *__restrict__ off,
+                                                        const TIO *__restrict__ msk, TIO *__restrict__ out, long total,
                                                         Dcnv3Geo q, T offset_scale)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -46,20 +50,20 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T *__restrict__ in
     const int K = q.kh * q.kw;
     const int p0_w = ((q.dw * (q.kw - 1)) >> 1) - q.pw + x * q.sw;
     const int p0_h = ((q.dh * (q.kh - 1)) >> 1) - q.ph + y * q.sh;
-    const T p0_w_ = (T)p0_w - (T)((q.dw * (q.kw - 1)) >> 1) * offset_scale;
-    const T p0_h_ = (T)p0_h - (T)((q.dh * (q.kh - 1)) >> 1) * offset_scale;
+    const T p0_w_ = (T)p0_w - dcn_mul_rn<T>((T)((q.dw * (q.kw - 1)) >> 1), offset_scale);
+    const T p0_h_ = (T)p0_h - dcn_mul_rn<T>((T)((q.dh * (q.kh - 1)) >> 1), offset_scale);
     const long ws = (long)q.G * q.C, hs = (long)q.W * ws;
-    const T *im = in + b * q.H * hs + (long)g * q.C + cc * VEC;
-    const T *op = off + sidx * K * 2;
-    const T *mp = msk + sidx * K;
+    const TIO *im = in + b * q.H * hs + (long)g * q.C + cc * VEC;
+    const TIO *op = off + sidx * K * 2;
+    const TIO *mp = msk + sidx * K;
     T acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0;
     auto point = [&](int i, int j) {
-            const T off_w = op[0], off_h = op[1], wgt = mp[0];
+            const T off_w = (T)op[0], off_h = (T)op[1], wgt = (T)mp[0];
             op += 2; mp += 1;
-            const T loc_w = p0_w_ + ((T)(i * q.dw) + off_w) * offset_scale;
-            const T loc_h = p0_h_ + ((T)(j * q.dh) + off_h) * offset_scale;
+            const T loc_w = dcn_loc<T>(p0_w_, (T)(i * q.dw), off_w, offset_scale);
+            const T loc_h = dcn_loc<T>(p0_h_, (T)(j * q.dh), off_h, offset_scale);
             const bool ok = loc_h > (T)-1 && loc_w > (T)-1 && loc_h < (T)q.H && loc_w < (T)q.W;
             // a rejected location (possibly NaN / inf) never reaches the address arithmetic
             const int h_low = ok ? (int)floor_t<T>(loc_h) : 0, w_low = ok ? (int)floor_t<T>(loc_w) : 0;
@@ -67,18 +71,23 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T *__restrict__ in
             const bool u0 = ok && h_low >= 0, u1 = ok && h_low + 1 <= q.H - 1, l0 = w_low >= 0, l1 = w_low + 1 <= q.W - 1;
             const int y0 = min(max(h_low, 0), q.H - 1), y1 = min(max(h_low + 1, 0), q.H - 1);
             const int x0 = min(max(w_low, 0), q.W - 1), x1 = min(max(w_low + 1, 0), q.W - 1);
-            const T *c1 = im + y0 * hs + x0 * ws, *c2 = im + y0 * hs + x1 * ws, *c3 = im + y1 * hs + x0 * ws,
-                    *c4 = im + y1 * hs + x1 * ws;
+            const TIO *c1 = im + y0 * hs + x0 * ws, *c2 = im + y0 * hs + x1 * ws, *c3 = im + y1 * hs + x0 * ws,
+                      *c4 = im + y1 * hs + x1 * ws;
             const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
             T v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-            if (VEC == 4 && sizeof(T) == 4) {
+            if constexpr (VEC == 4 && sizeof(TIO) == 4) {
                 *reinterpret_cast<float4_t *>(v1) = *reinterpret_cast<const float4_t *>(c1);
                 *reinterpret_cast<float4_t *>(v2) = *reinterpret_cast<const float4_t *>(c2);
                 *reinterpret_cast<float4_t *>(v3) = *reinterpret_cast<const float4_t *>(c3);
                 *reinterpret_cast<float4_t *>(v4) = *reinterpret_cast<const float4_t *>(c4);
+            } else if constexpr (VEC == 4 && sizeof(TIO) == 2) {   // four halves = one 8-byte load per corner
+                const half4_t h1 = *reinterpret_cast<const half4_t *>(c1), h2 = *reinterpret_cast<const half4_t *>(c2);
+                const half4_t h3 = *reinterpret_cast<const half4_t *>(c3), h4 = *reinterpret_cast<const half4_t *>(c4);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { v1[v] = (T)h1[v]; v2[v] = (T)h2[v]; v3[v] = (T)h3[v]; v4[v] = (T)h4[v]; }
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { v1[v] = c1[v]; v2[v] = c2[v]; v3[v] = c3[v]; v4[v] = c4[v]; }
+                for (int v = 0; v < VEC; ++v) { v1[v] = (T)c1[v]; v2[v] = (T)c2[v]; v3[v] = (T)c3[v]; v4[v] = (T)c4[v]; }
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -96,29 +105,32 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T *__restrict__ in
         for (int i = 0; i < q.kw; ++i)
             for (int j = 0; j < q.kh; ++j) point(i, j);
     }
-    T *o = out + sidx * q.C + cc * VEC;
-    if (VEC == 4 && sizeof(T) == 4) {
+    TIO *o = out + sidx * q.C + cc * VEC;
+    if constexpr (VEC == 4 && sizeof(TIO) == 4) {
         *reinterpret_cast<float4_t *>(o) = *reinterpret_cast<const float4_t *>(acc);
+    } else if constexpr (VEC == 4 && sizeof(TIO) == 2) {
+        const half4_t h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};   // round to nearest even, once
+        *reinterpret_cast<half4_t *>(o) = h;
     } else {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+        for (int v = 0; v < VEC; ++v) o[v] = (TIO)acc[v];
     }
 }
 
-template <typename T>
-int dcnv3_launch(const T *in, const T *off, const T *msk, Dcnv3Geo q, T offset_scale, T *out, hipStream_t st)
+template <typename TIO, typename T>
+int dcnv3_launch(const TIO *in, const TIO *off, const TIO *msk, Dcnv3Geo q, T offset_scale, TIO *out, hipStream_t st)
 {
     const long pix = (long)q.N * q.Ho * q.Wo * q.G;
     if (pix == 0 || q.C == 0) return VLLM_OK;
-    const bool vec = sizeof(T) == 4 && q.C % 4 == 0 && aligned16(in) && aligned16(out);
+    const bool vec = sizeof(TIO) <= 4 && q.C % 4 == 0 && aligned16(in) && aligned16(out);
     const long total = pix * (vec ? q.C / 4 : q.C);
     VLLM_REQUIRE(total < (1L << 40), "dcnv3: too many output elements");
     const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
     const bool k3 = q.kh == 3 && q.kw == 3;
-    if (vec && k3) VLLM_LAUNCH((dcnv3_fwd_kernel<T, 4, true>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
-    else if (vec) VLLM_LAUNCH((dcnv3_fwd_kernel<T, 4, false>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
-    else if (k3) VLLM_LAUNCH((dcnv3_fwd_kernel<T, 1, true>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
-    else VLLM_LAUNCH((dcnv3_fwd_kernel<T, 1, false>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
+    if (vec && k3) VLLM_LAUNCH((dcnv3_fwd_kernel<TIO, T, 4, true>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
+    else if (vec) VLLM_LAUNCH((dcnv3_fwd_kernel<TIO, T, 4, false>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
+    else if (k3) VLLM_LAUNCH((dcnv3_fwd_kernel<TIO, T, 1, true>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
+    else VLLM_LAUNCH((dcnv3_fwd_kernel<TIO, T, 1, false>), grid, block, 0, st, in, off, msk, out, total, q, offset_scale);
     VLLM_CHECK_LAUNCH("dcnv3_fwd_kernel");
     return VLLM_OK;
 }
@@ -152,7 +164,7 @@ extern "C" int vllm_dcnv3_forward_f32(const float *input, const float *offset, c
         if (mode <= 2 && dcnv3_pipe_ok(q)) return dcnv3_pipe_launch(input, offset, mask, q, offset_scale, out, mode == 2, (hipStream_t)stream);
         return dcnv3_tiled_launch(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
     }
-    return dcnv3_launch<float>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
+    return dcnv3_launch<float, float>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
 }
 
 extern "C" int vllm_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, int N, int H, int W,
@@ -163,5 +175,21 @@ extern "C" int vllm_dcnv3_forward_f64(const double *input, const double *offset,
     if (int e = make_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
     if (N == 0) return VLLM_OK;
     VLLM_REQUIRE(input && offset && mask && out, "dcnv3_forward_f64: null pointer");
-    return dcnv3_launch<double>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
+    return dcnv3_launch<double, double>(input, offset, mask, q, offset_scale, out, (hipStream_t)stream);
+}
+
+// Half precision (round 5; the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69): IEEE binary16 tensors as
+// uint16_t bit patterns, fp32 arithmetic (opmath_t = float), the output rounded once -- the result of running the fp32 operator on
+// the widened operands and rounding it, which is what the parity test checks bit for bit.
+extern "C" int vllm_dcnv3_forward_f16(const uint16_t *input, const uint16_t *offset, const uint16_t *mask, int N, int H, int W,
+                                      int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                      float offset_scale, uint16_t *out, vllm_stream_t stream)
+{
+    Dcnv3Geo q;
+    if (int e = make_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
+    if (N == 0) return VLLM_OK;
+    VLLM_REQUIRE(input && offset && mask && out, "dcnv3_forward_f16: null pointer");
+    return dcnv3_launch<_Float16, float>(reinterpret_cast<const _Float16 *>(input), reinterpret_cast<const _Float16 *>(offset),
+                                         reinterpret_cast<const _Float16 *>(mask), q, offset_scale, reinterpret_cast<_Float16 *>(out),
+                                         (hipStream_t)stream);
 }

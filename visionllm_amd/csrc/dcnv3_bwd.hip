@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_vec_kernel(const T *__restrict_
     const int K = q.kh * q.kw;
     const int p0_w = ((q.dw * (q.kw - 1)) >> 1) - q.pw + x * q.sw;
     const int p0_h = ((q.dh * (q.kh - 1)) >> 1) - q.ph + y * q.sh;
-    const T p0_w_ = (T)p0_w - (T)((q.dw * (q.kw - 1)) >> 1) * offset_scale;
-    const T p0_h_ = (T)p0_h - (T)((q.dh * (q.kh - 1)) >> 1) * offset_scale;
+    const T p0_w_ = (T)p0_w - dcn_mul_rn<T>((T)((q.dw * (q.kw - 1)) >> 1), offset_scale);
+    const T p0_h_ = (T)p0_h - dcn_mul_rn<T>((T)((q.dh * (q.kh - 1)) >> 1), offset_scale);
     const long ws = (long)q.G * q.C, hs = (long)q.W * ws;
     const long imo = b * q.H * hs + (long)g * q.C + cc * 4;
     const T *im = in + imo;
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_vec_kernel(const T *__restrict_
         for (int j = 0; j < q.kh; ++j) {
             const T off_w = op[0], off_h = op[1], wgt = mp[0];
             op += 2; mp += 1;
-            const T loc_w = p0_w_ + ((T)(i * q.dw) + off_w) * offset_scale;
-            const T loc_h = p0_h_ + ((T)(j * q.dh) + off_h) * offset_scale;
+            const T loc_w = dcn_loc<T>(p0_w_, (T)(i * q.dw), off_w, offset_scale);
+            const T loc_h = dcn_loc<T>(p0_h_, (T)(j * q.dh), off_h, offset_scale);
             const BwdPoint<T> p = bwd_point<T>(loc_h, loc_w, q.H, q.W);
             const long o1 = p.y0 * hs + p.x0 * ws, o2 = p.y0 * hs + p.x1 * ws, o3 = p.y1 * hs + p.x0 * ws, o4 = p.y1 * hs + p.x1 * ws;
             const T w1 = p.hh * p.hw, w2 = p.hh * p.lw, w3 = p.lh * p.hw, w4 = p.lh * p.lw;
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_generic_kernel(const T *__restr
     const int K = q.kh * q.kw;
     const int p0_w = ((q.dw * (q.kw - 1)) >> 1) - q.pw + x * q.sw;
     const int p0_h = ((q.dh * (q.kh - 1)) >> 1) - q.ph + y * q.sh;
-    const T p0_w_ = (T)p0_w - (T)((q.dw * (q.kw - 1)) >> 1) * offset_scale;
-    const T p0_h_ = (T)p0_h - (T)((q.dh * (q.kh - 1)) >> 1) * offset_scale;
+    const T p0_w_ = (T)p0_w - dcn_mul_rn<T>((T)((q.dw * (q.kw - 1)) >> 1), offset_scale);
+    const T p0_h_ = (T)p0_h - dcn_mul_rn<T>((T)((q.dh * (q.kh - 1)) >> 1), offset_scale);
     const long ws = (long)q.G * q.C, hs = (long)q.W * ws;
     const long imo = b * q.H * hs + (long)g * q.C;
     const T *im = in + imo;
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_generic_kernel(const T *__restr
     for (int i = 0; i < q.kw; ++i)
         for (int j = 0; j < q.kh; ++j) {
             const T off_w = off[wp * 2], off_h = off[wp * 2 + 1], wgt = msk[wp];
-            const T loc_w = p0_w_ + ((T)(i * q.dw) + off_w) * offset_scale;
-            const T loc_h = p0_h_ + ((T)(j * q.dh) + off_h) * offset_scale;
+            const T loc_w = dcn_loc<T>(p0_w_, (T)(i * q.dw), off_w, offset_scale);
+            const T loc_h = dcn_loc<T>(p0_h_, (T)(j * q.dh), off_h, offset_scale);
             const BwdPoint<T> p = bwd_point<T>(loc_h, loc_w, q.H, q.W);
             const long o1 = p.y0 * hs + p.x0 * ws, o2 = p.y0 * hs + p.x1 * ws, o3 = p.y1 * hs + p.x0 * ws, o4 = p.y1 * hs + p.x1 * ws;
             const T w1 = p.hh * p.hw, w2 = p.hh * p.lw, w3 = p.lh * p.hw, w4 = p.lh * p.lw;
@@ -272,4 +272,97 @@ extern "C" int vllm_dcnv3_backward_f64(const double *input, const double *offset
     if (N == 0) return VLLM_OK;
     VLLM_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "dcnv3_backward_f64: null pointer");
     return dcnv3_bwd_launch<double>(input, offset, mask, grad_output, q, offset_scale, grad_input, grad_offset, grad_mask, (hipStream_t)stream);
+}
+
+// ---- half precision (round 5): the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF (dcnv3_cuda.cu:147) with fp32 arithmetic.
+// The four operands are widened into the caller's fp32 workspace, the fp32 backward above runs on them (the windowed MFMA kernel for
+// group channels 32), the three gradients are rounded to half once.  (The reference accumulates grad_input with HALF atomics, one
+// rounding per contribution and an order-dependent result; one rounding of the fp32 sum is the better-conditioned form of the same
+// quantity, and what the parity test checks against dcnv3_core_pytorch's autograd.)
+namespace vllm {
+namespace {
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void widen_f16_kernel(const _Float16 *__restrict__ src, float *__restrict__ dst, long n)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const half8_t h = *reinterpret_cast<const half8_t *>(src + i);
+        float4_t a = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, b = {(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+        *reinterpret_cast<float4_t *>(dst + i) = a;
+        *reinterpret_cast<float4_t *>(dst + i + 4) = b;
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = (float)src[j];
+    }
+}
+__global__ __launch_bounds__(256) void narrow_f16_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, long n)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4_t a = *reinterpret_cast<const float4_t *>(src + i), b = *reinterpret_cast<const float4_t *>(src + i + 4);
+        const half8_t h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+        *reinterpret_cast<half8_t *>(dst + i) = h;
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = (_Float16)src[j];
+    }
+}
+int widen(const uint16_t *src, float *dst, long n, hipStream_t st)
+{
+    if (n == 0) return VLLM_OK;
+    VLLM_LAUNCH(widen_f16_kernel, dim3((unsigned)ceil_div(n, 2048)), dim3(256), 0, st, reinterpret_cast<const _Float16 *>(src), dst, n);
+    VLLM_CHECK_LAUNCH("widen_f16_kernel");
+    return VLLM_OK;
+}
+int narrow(const float *src, uint16_t *dst, long n, hipStream_t st)
+{
+    if (n == 0) return VLLM_OK;
+    VLLM_LAUNCH(narrow_f16_kernel, dim3((unsigned)ceil_div(n, 2048)), dim3(256), 0, st, src, reinterpret_cast<_Float16 *>(dst), n);
+    VLLM_CHECK_LAUNCH("narrow_f16_kernel");
+    return VLLM_OK;
+}
+inline long pad4(long n) { return (n + 3) & ~3L; }   // every fp32 slab of the workspace starts 16-byte aligned
+}  // namespace
+}  // namespace vllm
+
+extern "C" long vllm_dcnv3_backward_f16_workspace(int N, int H, int W, int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw)
+{
+    Dcnv3Geo q;
+    if (bwd_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return -1;
+    const long n_in = (long)N * H * W * G * C, n_out = (long)N * q.Ho * q.Wo * G * C, n_msk = (long)N * q.Ho * q.Wo * G * kh * kw;
+    return (2 * pad4(n_in) + pad4(n_out) + 2 * pad4(2 * n_msk) + 2 * pad4(n_msk)) * (long)sizeof(float);
+}
+
+extern "C" int vllm_dcnv3_backward_f16(const uint16_t *input, const uint16_t *offset, const uint16_t *mask, const uint16_t *grad_output, int N,
+                                       int H, int W, int G, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                       float offset_scale, uint16_t *grad_input, uint16_t *grad_offset, uint16_t *grad_mask,
+                                       void *workspace, long workspace_bytes, vllm_stream_t stream)
+{
+    Dcnv3Geo q;
+    if (int e = bwd_geo(q, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw)) return e;
+    if (N == 0) return VLLM_OK;
+    VLLM_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "dcnv3_backward_f16: null pointer");
+    const long need = vllm_dcnv3_backward_f16_workspace(N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw);
+    VLLM_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), "dcnv3_backward_f16: workspace of %ld bytes (16-byte aligned) required", need);
+    const long n_in = (long)N * H * W * G * C, n_out = (long)N * q.Ho * q.Wo * G * C, n_msk = (long)N * q.Ho * q.Wo * G * kh * kw;
+    hipStream_t st = (hipStream_t)stream;
+    float *w = static_cast<float *>(workspace);
+    float *in32 = w; w += pad4(n_in);
+    float *gin32 = w; w += pad4(n_in);
+    float *go32 = w; w += pad4(n_out);
+    float *off32 = w; w += pad4(2 * n_msk);
+    float *goff32 = w; w += pad4(2 * n_msk);
+    float *msk32 = w; w += pad4(n_msk);
+    float *gmsk32 = w;
+    if (int e = widen(input, in32, n_in, st)) return e;
+    if (int e = widen(offset, off32, 2 * n_msk, st)) return e;
+    if (int e = widen(mask, msk32, n_msk, st)) return e;
+    if (int e = widen(grad_output, go32, n_out, st)) return e;
+    if (hipMemsetAsync(gin32, 0, (size_t)n_in * sizeof(float), st) != hipSuccess) {
+        set_error("dcnv3_backward_f16: hipMemsetAsync failed");
+        return VLLM_ELAUNCH;
+    }
+    if (int e = vllm_dcnv3_backward_f32(in32, off32, msk32, go32, N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw, offset_scale, gin32, goff32, gmsk32, stream))
+        return e;
+    if (int e = narrow(gin32, grad_input, n_in, st)) return e;
+    if (int e = narrow(goff32, grad_offset, 2 * n_msk, st)) return e;
+    return narrow(gmsk32, grad_mask, n_msk, st);
 }

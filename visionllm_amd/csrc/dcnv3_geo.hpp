@@ -4,4 +4,22 @@ namespace vllm {
 struct Dcnv3Geo {
     int N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
 };
+
+// ONE definition of a sampling location for every DCNv3 kernel (forward gather / tiled / pipelined, backward gather / windowed):
+//   loc = p0 + (i * dilation + offset) * offset_scale          (dcnv3_im2col_cuda.cuh:256-259)
+// with the product ROUNDED ON ITS OWN.  Under hipcc's default -ffp-contract=fast the backend may or may not fuse the multiply into
+// the add, kernel by kernel; floor(loc) picks the cell and grad_offset is discontinuous across a cell border, so two kernels that
+// disagree in the last bit of loc can disagree about a whole cell for a location next to an integer.  The empty asm
+// makes the product opaque (zero instructions), as mul_rn of msda_sample.hpp does for the MSDA kernels.
+#ifdef __HIPCC__
+template <typename T>
+__device__ __forceinline__ T dcn_mul_rn(T a, T b)
+{
+    T p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+template <typename T>
+__device__ __forceinline__ T dcn_loc(T p0, T i_dil, T off, T scale) { return p0 + dcn_mul_rn<T>(i_dil + off, scale); }
+#endif
 }  // namespace vllm

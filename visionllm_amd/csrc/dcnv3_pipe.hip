@@ -94,7 +94,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
     const int so = k * 16;                                  // this lane's 16 bytes inside each 64-byte half of a pixel row
     const int sub = lane % LPP, lpx = lane / LPP;          // DMA roles
     const int p0w_i = ((q.dw * (q.kw - 1)) >> 1) - q.pw, p0h_i = ((q.dh * (q.kh - 1)) >> 1) - q.ph;
-    const float cw = (float)((q.dw * (q.kw - 1)) >> 1) * offset_scale, ch = (float)((q.dh * (q.kh - 1)) >> 1) * offset_scale;
+    const float cw = dcn_mul_rn<float>((float)((q.dw * (q.kw - 1)) >> 1), offset_scale), ch = dcn_mul_rn<float>((float)((q.dh * (q.kh - 1)) >> 1), offset_scale);
     float pi_[3], pj_[3];                                   // kernel_w outer, kernel_h inner (:246-249)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
                 if (p < K && nxt.pok) {
                     const float2_t o2 = o2f[r];
                     const float wgt = wgf[r];
-                    const float loc_w = p0w + (pi_[r] + o2.x) * offset_scale;
-                    const float loc_h = p0h + (pj_[r] + o2.y) * offset_scale;
+                    const float loc_w = dcn_loc<float>(p0w, pi_[r], o2.x, offset_scale);
+                    const float loc_h = dcn_loc<float>(p0h, pj_[r], o2.y, offset_scale);
                     const bool ok = loc_h > -1.f && loc_w > -1.f && loc_h < (float)q.H && loc_w < (float)q.W;
                     if (ok) {   // (a rejected location, possibly NaN / inf, never reaches the integer arithmetic)
                         const int h = (int)floorf(loc_h), w = (int)floorf(loc_w);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(DT_THREADS, (2 * DT_WAVES + 3) / 4) void dcnv3_fwd_
     const long ipx = (items + 7) >> 3;
     const int bpx = gridDim.x >> 3;
     const int p0w_i = ((q.dw * (q.kw - 1)) >> 1) - q.pw, p0h_i = ((q.dh * (q.kh - 1)) >> 1) - q.ph;
-    const float cw = (float)((q.dw * (q.kw - 1)) >> 1) * offset_scale, ch = (float)((q.dh * (q.kh - 1)) >> 1) * offset_scale;
+    const float cw = dcn_mul_rn<float>((float)((q.dw * (q.kw - 1)) >> 1), offset_scale), ch = dcn_mul_rn<float>((float)((q.dh * (q.kh - 1)) >> 1), offset_scale);
     int bsel = 0;
     unsigned pacc[8] = {};   // (dead in the production instantiation)
     unsigned tprev = PROF ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(DT_THREADS, (2 * DT_WAVES + 3) / 4) void dcnv3_fwd_
             if (p < K && pok) {
                 const float2_t o2 = o2c[r];
                 const float wgt = wgc[r];
-                const float loc_w = p0w + (pi_[r] + o2.x) * offset_scale;
-                const float loc_h = p0h + (pj_[r] + o2.y) * offset_scale;
+                const float loc_w = dcn_loc<float>(p0w, pi_[r], o2.x, offset_scale);
+                const float loc_h = dcn_loc<float>(p0h, pj_[r], o2.y, offset_scale);
                 const bool ok = loc_h > -1.f && loc_w > -1.f && loc_h < (float)q.H && loc_w < (float)q.W;
                 if (ok) {   // (a rejected location, possibly NaN / inf, never reaches the integer arithmetic)
                     const int h = (int)floorf(loc_h), w = (int)floorf(loc_w);

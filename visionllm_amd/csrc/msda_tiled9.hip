@@ -30,9 +30,9 @@
 #include "msda_tiled6_helpers.hpp"
 
 // Timing-only ablation builds: -DT9_ABL=<mask>.  1: no multiply-adds in the gather, 2: no LDS reads in the gather,
-// 4: no window DMA, 8: no output stores, 16: no gather at all, 32: no point arithmetic (P1 skipped).
+// 4: no window DMA, 8: no output stores, 16: no gather at all, 32: no point arithmetic (P1 skipped), 64: conflict-free gather reads.
 #ifndef T9_EARLY      // levels of pass 0 a team gathers at the END of its preparing half (behind a meeting point of its own), 0: none
-#define T9_EARLY 1
+#define T9_EARLY 3     // (round 5: with the leaner preparing half three levels balance the halves: 410.9 vs 432.0 us with one, profiles/r05_msda_diet.txt)
 #endif
 #ifndef T9_ABL
 #define T9_ABL 0
@@ -46,8 +46,11 @@
 #ifndef T9_TW         // waves per team: 4 (8 waves, 2 per SIMD, 3 passes of 64 slots) or 6 (12 waves, 3 per SIMD, 2 passes of 96 slots:
 #define T9_TW 6       // generation 8's shape with this file's straight-line halves and pipelined gather): the library's build
 #endif
+#ifndef T9_DIET       // round 5, instruction diet of the preparing half (bit mask; profiles/r05_msda_diet.txt): 1 incremental window DMA,
+#define T9_DIET 63    // 2 leaner point arithmetic + packed box minima, 4 item decode by multiply-high, 8 six-product weights, 16 contiguous DMA runs per wave, 32 layout fast path + reciprocal magic, (64: slot words carried in a register -- spills 3 VGPRs, not in the default)
+#endif
 #ifndef T9_GPRIO      // s_setprio of a wave while it gathers
-#define T9_GPRIO 1
+#define T9_GPRIO 2
 #endif
 
 namespace vllm {
@@ -170,6 +173,11 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         return rr | ((lo >> (4 - rr)) << 2) | ((lo & ((16 >> rr) - 1)) << 6) | ((s >= n_slots ? 1 : 0) << 10);
     };
     const int v0k = (int)lsi[min(lane & 3, L - 1)];   // (the one per-lane constant that is a memory load: carried)
+#if T9_DIET & 64
+    // (round 5: the lane's two slot words, 11 bits each, carried in ONE register instead of re-derived per item: ~25 VALU per pass)
+    int sinfo_pk = 0;
+    if (NP == 2) sinfo_pk = sinfo_of(0, lane) | (sinfo_of(1, lane) << 11);
+#endif
 
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
     if (tid < 32) s_box[tid] = T6_BIG;
@@ -196,9 +204,23 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         const int q = ok ? sQ + y * sW + x : (ty * 8) * W0 + tx * 16;
         return (unsigned)((b * Lq + q) * M + m);
     };
+#if T9_DIET & 4
+    // Round 5: the three divisions of an item number (block-uniform, once per item and wave: ~25 scalar / vector instructions each
+    // through the compiler's reciprocal sequence) by multiply-high with magic numbers made once per launch.  floor(n / d) ==
+    // mulhi(n, floor(2^32 / d) + 1) for n * d < 2^32; every dividend here is < n_items and n_items * max(d) < 2^32 is checked
+    // (otherwise the magic numbers are 0 and the plain divisions run).
+    const bool fastdiv = (unsigned long long)n_items * (unsigned)max(max(n_tiles, M), ntx0) < (1ull << 32);
+    const unsigned mg_tiles = fastdiv ? (unsigned)(0xffffffffu / (unsigned)n_tiles) + 1u : 0u;
+    const unsigned mg_M = fastdiv ? (unsigned)(0xffffffffu / (unsigned)M) + 1u : 0u;
+    const unsigned mg_ntx = fastdiv ? (unsigned)(0xffffffffu / (unsigned)ntx0) + 1u : 0u;
+    auto udiv = [](unsigned n, unsigned d, unsigned mg) { return mg ? __umulhi(n, mg) : n / d; };
+#else
+    auto udiv = [](unsigned n, unsigned d, unsigned) { return n / d; };
+    const unsigned mg_tiles = 0, mg_M = 0, mg_ntx = 0;
+#endif
     auto decode = [&](unsigned item, int &b, int &m, int &ty, int &tx) {
-        const unsigned bm = item / (unsigned)n_tiles, t = item - bm * (unsigned)n_tiles;
-        const unsigned bb = bm / (unsigned)M, yy = t / (unsigned)ntx0;
+        const unsigned bm = udiv(item, (unsigned)n_tiles, mg_tiles), t = item - bm * (unsigned)n_tiles;
+        const unsigned bb = udiv(bm, (unsigned)M, mg_M), yy = udiv(t, (unsigned)ntx0, mg_ntx);
         b = __builtin_amdgcn_readfirstlane((int)bb); m = __builtin_amdgcn_readfirstlane((int)(bm - bb * (unsigned)M));
         ty = __builtin_amdgcn_readfirstlane((int)yy); tx = __builtin_amdgcn_readfirstlane((int)(t - yy * (unsigned)ntx0));
     };
@@ -220,7 +242,11 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             const int kk = min(ln & 3, L - 1);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
+#if T9_DIET & 64
+                npr[p] = pair_of(NP == 2 ? (sinfo_pk >> (11 * p)) & 0x7ff : sinfo_of(p, ln), nb, nm, ty, tx, nqok[p]);
+#else
                 npr[p] = pair_of(sinfo_of(p, ln), nb, nm, ty, tx, nqok[p]);
+#endif
                 const unsigned e = (npr[p] * (unsigned)L + (unsigned)kk) * PT;
                 lc0[p] = *reinterpret_cast<const float4_t *>(loc + (size_t)e * 2);
                 lc1[p] = *reinterpret_cast<const float4_t *>(loc + (size_t)e * 2 + 4);
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     bool qokc[NP] = {};
     float w1[NP][4] = {}, w2[NP][4] = {}, w3[NP][4] = {}, w4[NP][4] = {};
     int o[NP][4] = {};
-    unsigned okm[NP] = {};
+    [[maybe_unused]] unsigned okm[NP] = {};
     int4 bx = {0, 0, 0, 0};
     int lay = 0;
     float acc_e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // T9_EARLY: pass 0's sums of the levels gathered before the swap
@@ -250,6 +276,9 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         const float *vbc = value + ((size_t)cb * S * M + cm) * D;
         const int ln = lane_now();
         const int cA = chunk_of(ln), cA0 = cA + (int)lds_addr(smem);
+        // (timing-only ablation 64: every quad reads a fixed pixel whose parity is its quad number's -- the four quads of a
+        //  ds_read_b128 lane group then hit four different bank sets: what a conflict-free window layout would buy)
+        const int cfree = cA0 + (T6_ZPX + ((ln >> 2) & 1)) * 128;
         // (wave-uniform) which levels this call gathers, and their window pitch in bytes
         bool act[4];
         int pit[4];
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         // newer reads are outstanding.
 #define T9_STEP(SET, I_, LQ, CNT, NX, NI, NLQ)                                                                    \
     {                                                                                                            \
-        int b0_ = (NX) ? qbi<NLQ>(oc[NI]) + cA0 : 0, b1_ = b0_ ^ 64;                                              \
+        int b0_ = (NX) ? ((T9_ABL & 64) ? (qbi<NLQ>(oc[NI]) & 0) + cfree : qbi<NLQ>(oc[NI]) + cA0) : 0, b1_ = b0_ ^ 64; \
         int b0p_ = b0_ + pit[NLQ], b1p_ = b1_ + pit[NLQ];                                                        \
         float e1 = qbf<LQ>(w1c[I_]), e2 = qbf<LQ>(w2c[I_]), e3 = qbf<LQ>(w3c[I_]), e4 = qbf<LQ>(w4c[I_]);        \
         asm volatile("" : "+v"(b0_), "+v"(b1_), "+v"(b0p_), "+v"(b1p_), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4)); \
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     }
 #define T9_RD(SET, I_, LQ)                                                                                       \
     {                                                                                                            \
-        const int b0_ = qbi<LQ>(oc[I_]) + cA0, b1_ = b0_ ^ 64;                                                    \
+        const int b0_ = (T9_ABL & 64) ? (qbi<LQ>(oc[I_]) & 0) + cfree : qbi<LQ>(oc[I_]) + cA0, b1_ = b0_ ^ 64;     \
         t9_read(SET, b0_, b0_ + pit[LQ], b1_, b1_ + pit[LQ]);                                                    \
     }
         // NO control flow between a read and the wait that releases it.  A first version requested the next level's first two
@@ -405,6 +434,58 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
         const int sub8 = ln & 7;
+#if T9_DIET & 16
+        // Round 5, second step: a wave takes a CONTIGUOUS run of 8-pixel groups of the concatenated windows (call sites), here groups
+        // [phase, np) of this level: with groups dealt round-robin every wave set up every level (4 x ~68 instructions per item,
+        // twice the cost of the rounds themselves); a contiguous sixth of the list touches 1-2 levels.  The walk is the incremental
+        // one below with a step of 8 pixels.
+        (void)g0;
+        {
+            const int pixi = uni(phase) * 8 + (ln >> 3);
+            const int wy0 = (int)(__umul24((unsigned)pixi, magic) >> 20);          // (pixi < 2^11, magic <= 2^20 + 1)
+            int gx = x0 + (pixi - __mul24(wy0, ww));
+            unsigned voff = ((unsigned)(__mul24(y0 + wy0, Wl) + gx) * MD + (unsigned)sub8 * 4u) * 4u;
+            const int dq = (int)((8u * magic) >> 20), dr = 8 - dq * ww;             // (wave-uniform; dr < ww)
+            const unsigned stepN = (unsigned)(dq * Wl + dr) * (unsigned)uni((int)MD) * 4u;
+            const unsigned stepC = stepN + (unsigned)(Wl - ww) * (unsigned)uni((int)MD) * 4u;
+            const int xend = x0 + ww;
+            // (the three level constants of the carry live in VECTOR registers through the loop, made opaque: left to itself the
+            //  compiler re-materialises them from scalar registers every round -- a select cannot take two scalar operands)
+            int wwv = ww;
+            unsigned sNv = stepN, sCv = stepC;
+            asm volatile("" : "+v"(wwv), "+v"(sNv), "+v"(sCv));
+            for (int g = uni(phase); g < np; ++g) {
+                const unsigned vo = (unsigned)gx < (unsigned)Wl ? voff : 0xfffffff0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + g * 1024), 16, (int)vo, 0, 0, 0);
+                gx += dr;
+                const bool carry = gx >= xend;
+                gx -= carry ? wwv : 0;
+                voff += carry ? sCv : sNv;
+            }
+        }
+#elif T9_DIET & 1
+        // Round 5: the lane's pixel walks the window INCREMENTALLY.  Round 4 re-derived (row, column) of pixel pix0 + lane / 8 from
+        // scratch every round -- a magic-number division and two more 32-bit multiplies (quarter rate) plus a 64-bit multiply-add:
+        // 23 instructions per 1 KiB.  A round advances every lane by TW * 8 pixels = dq rows + dr columns (level constants); the
+        // column carries into the row at most once (dr < ww).  Rows outside the map fall outside the buffer descriptor (hardware
+        // zero fill, also for the wrapped "negative" offsets of row -1); only the column needs a test.  8 VALU + 1 load per round.
+        const int pixi = uni(g0) * 8 + (ln >> 3);
+        const int wy0 = (int)(__umul24((unsigned)pixi, magic) >> 20);          // (pixi < 64, magic <= 2^20 + 1: 24-bit operands, full rate)
+        int gx = x0 + (pixi - __mul24(wy0, ww));
+        unsigned voff = ((unsigned)(__mul24(y0 + wy0, Wl) + gx) * MD + (unsigned)sub8 * 4u) * 4u;
+        const int dq = (int)(((unsigned)(TW * 8) * magic) >> 20), dr = TW * 8 - dq * ww;   // (wave-uniform)
+        const unsigned stepN = (unsigned)(dq * Wl + dr) * (unsigned)uni((int)MD) * 4u;
+        const unsigned stepC = stepN + (unsigned)(Wl - ww) * (unsigned)uni((int)MD) * 4u;
+        const int xend = x0 + ww;
+        for (int pix0 = uni(g0) * 8; pix0 < np; pix0 += TW * 8) {
+            const unsigned vo = (unsigned)gx < (unsigned)Wl ? voff : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + pix0 * 128), 16, (int)vo, 0, 0, 0);
+            gx += dr;
+            const bool carry = gx >= xend;
+            gx -= carry ? ww : 0;
+            voff += carry ? stepC : stepN;
+        }
+#else
         for (int pix0 = uni(g0) * 8; pix0 < np; pix0 += TW * 8) {
             const int pix = pix0 + (ln >> 3);
             const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
@@ -413,6 +494,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + pix0 * 128), 16, (int)voff, 0, 0, 0);
         }
+#endif
     };
 
     // a team's meeting point: wait until `target` arrivals have been counted.  Bounded: the four waves of a team always take the
@@ -458,6 +540,61 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             if (cv && !(T9_ABL & 32)) {
                 const int kk = min(k, L - 1);
                 const int Hk = EXACT ? H0 >> kk : s_dim[kk], Wk = EXACT ? W0 >> kk : s_dim[4 + kk];
+#if T9_DIET & 2
+                // Round 5 form of the point arithmetic (profiles/r05_msda_diet.txt: 53 -> ~34 instructions per point).  Same values
+                // as sample_point() for every accepted point: the acceptance test is the reference's four comparisons, floor() is
+                // taken once and reused as the float the fractions are measured from ((float)(int)floor(x) == floor(x) for the
+                // coordinates a map can have), the integer parts only ever reach the packed word `o`.  What changed:
+                //   * ONE select per quantity that feeds the weights (the two fractions and the attention weight become 0 for a
+                //     rejected point, all four products are then exactly 0) instead of one per weight and per integer part;
+                //   * a rejected point is o = -1 (no separate mask word; the offsets below test the sign);
+                //   * the box: both coordinates of `o` at once -- v_pk_min_u16 (a rejected point is 0xffff, 0xffff: never the minimum)
+                //     and v_pk_max_i16 (a rejected point is -1, -1: never the maximum; accepted fields are 0 .. H), no selects, no
+                //     negations; the packed pair goes through the two DPP steps and is unpacked by the 16 lanes that do the ds_min.
+                int rmin = -1, rmax = -1;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bool lane_ok = qokc[p] && k < L;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float lx = i < 2 ? lc0[p][2 * i] : lc1[p][2 * i - 4], ly = i < 2 ? lc0[p][2 * i + 1] : lc1[p][2 * i - 3];
+                        const float h_im = sub_rn(mul_rn(ly, (float)Hk), 0.5f), w_im = sub_rn(mul_rn(lx, (float)Wk), 0.5f);
+                        const bool ok = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hk) && (w_im < (float)Wk) && lane_ok;
+                        const float hf = floorf(h_im), wf = floorf(w_im);
+                        const float lh = ok ? h_im - hf : 0.f, lw = ok ? w_im - wf : 0.f;
+                        const float a = ok ? la[p][i] : 0.f;
+                        const float hh = 1.f - lh, hw_ = 1.f - lw;
+#if T9_DIET & 8
+                        // (six products instead of eight: the attention weight goes into the two row factors first.  One rounding
+                        //  placed differently from the other kernels of the family, 1 ulp of a weight: inside the 2e-6 the tests
+                        //  allow between kernels, 4e-6 against the oracle)
+                        const float ta = hh * a, tb = lh * a;
+                        w1[p][i] = ta * hw_; w2[p][i] = ta * lw; w3[p][i] = tb * hw_; w4[p][i] = tb * lw;
+#else
+                        w1[p][i] = (hh * hw_) * a; w2[p][i] = (hh * lw) * a;
+                        w3[p][i] = (lh * hw_) * a; w4[p][i] = (lh * lw) * a;
+#endif
+                        const int oo = ok ? ((int)hf << 16) + (int)wf + 0x10001 : -1;
+                        o[p][i] = oo;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(rmin) : "v"(rmin), "v"(oo));
+                        asm("v_pk_max_i16 %0, %1, %2" : "=v"(rmax) : "v"(rmax), "v"(oo));
+                    }
+                }
+                {
+                    int t;
+                    t = __builtin_amdgcn_update_dpp(rmin, rmin, 0x124, 0xf, 0xf, false); asm("v_pk_min_u16 %0, %1, %2" : "=v"(rmin) : "v"(rmin), "v"(t));
+                    t = __builtin_amdgcn_update_dpp(rmin, rmin, 0x128, 0xf, 0xf, false); asm("v_pk_min_u16 %0, %1, %2" : "=v"(rmin) : "v"(rmin), "v"(t));
+                    t = __builtin_amdgcn_update_dpp(rmax, rmax, 0x124, 0xf, 0xf, false); asm("v_pk_max_i16 %0, %1, %2" : "=v"(rmax) : "v"(rmax), "v"(t));
+                    t = __builtin_amdgcn_update_dpp(rmax, rmax, 0x128, 0xf, 0xf, false); asm("v_pk_max_i16 %0, %1, %2" : "=v"(rmax) : "v"(rmax), "v"(t));
+                }
+                if ((lnA & 12) == 0 && rmax >= 0) {       // (rmax < 0: no accepted point of this level in this lane row)
+                    const unsigned a = lds_addr(s_box + team * 16 + k * 4);
+                    const int r0 = (int)((unsigned)rmin >> 16) - 1, r1 = 1 - (rmax >> 16);
+                    const int r2 = (rmin & 0xffff) - 1, r3 = 1 - (rmax & 0xffff);
+                    asm volatile("ds_min_i32 %0, %1\n\tds_min_i32 %0, %2 offset:4\n\tds_min_i32 %0, %3 offset:8\n\tds_min_i32 %0, %4 offset:12"
+                                 :: "v"(a), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+                }
+#else
                 int r0 = T6_BIG, r1 = T6_BIG, r2 = T6_BIG, r3 = T6_BIG;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
@@ -486,6 +623,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     asm volatile("ds_min_i32 %0, %1\n\tds_min_i32 %0, %2 offset:4\n\tds_min_i32 %0, %3 offset:8\n\tds_min_i32 %0, %4 offset:12"
                                  :: "v"(a), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
                 }
+#endif
             }
             T9_TICK(1)
             // ================= P2: layout beside the other team's item, LDS offsets, window DMA =================
@@ -505,7 +643,14 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 const int wwk = (-bx.w + 1) - bx.z + 1;
                 int np8k = anyk ? ((((-bx.y + 1) - bx.x + 1) * wwk + 7) & ~7) : 0;
                 if (anyk && wwk > T6_ZPX - 2) np8k = 0x10000;
+#if T9_DIET & 32
+                // floor(2^20 / ww) + 1 through the hardware reciprocal: 2^20 / ww is an integer (ww a power of two: exact in float) or
+                // at least 1 / ww away from one on either side, the float result is within 2^20 / ww * 2^-22 = 1 / (4 ww) of it --
+                // the same number as the integer division (~20 instructions with four quarter-rate multiplies) for every ww >= 1
+                const unsigned magick = (unsigned)(1048576.f * __builtin_amdgcn_rcpf((float)max(wwk, 1))) + 1u;
+#else
                 const unsigned magick = (1u << 20) / (unsigned)max(wwk, 1) + 1u;
+#endif
                 int cum[5] = {0, 0, 0, 0, 0};
                 magick_c = magick;
                 {
@@ -516,6 +661,29 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     const int limit = R - used_other;
                     int used = 0, lays[4];
                     late_l = -1; late_np = 0;
+#if T9_DIET & 32
+                    // Round 5: the common case -- every level fits beside the other team's item -- without the level-by-level
+                    // scalar walk (~120 scalar instructions per wave and item): the inclusive prefix sum of the four window sizes
+                    // on lanes 0 .. 3 (two DPP row shifts), one comparison of the total, bases / layout words computed on those
+                    // lanes and read back with eight v_readlane.  Anything else (a level that does not fit: late or from global
+                    // memory; a window wider than the zero strip, np8k = 0x10000 > limit) takes the walk below.
+                    int incl = np8k;
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1, lanes without a source add 0
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                    const int total = __builtin_amdgcn_readlane(incl, 3);
+                    const bool all_fit = total <= limit;
+                    if (all_fit) {
+                        const int basev = team ? R - incl : incl - np8k;
+                        const int layv = np8k > 0 ? (basev | (1 << 24)) : 0;
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) {
+                            lays[l] = __builtin_amdgcn_readlane(layv, l);
+                            cum[l + 1] = __builtin_amdgcn_readlane(incl, l);
+                        }
+                        used = total;
+                    } else
+#endif
+                    {
 #pragma unroll
                     for (int l = 0; l < 4; ++l) {
                         const int np = __builtin_amdgcn_readlane(np8k, l);
@@ -536,6 +704,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     } else {
                         late_l = -1;
                     }
+                    }
                     lay = sel4(k, lays[0], lays[1], lays[2], lays[3]);
                     if (tid == team * (TW * 64)) s_used[team] = used;
                 }
@@ -547,21 +716,41 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     for (int p = 0; p < NP; ++p)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
+#if T9_DIET & 2
+                            // (row * pitch by the 24-bit multiply-add -- full rate, the 32-bit product is quarter rate; the
+                            //  constants of the level folded into one; rejected points carry a negative word)
+                            const int cst = T6_ZPX + basek - (y0k + 1) * wwk - (x0k + 1);
+                            const int lin = __mul24((int)((unsigned)o[p][i] >> 16), wwk) + (o[p][i] & 0xffff);   // (hl + 1) * ww + (wl + 1)
+                            const int off = o[p][i] >= 0 ? (lin + cst) * 128 : 0;
+                            o[p][i] = hotk ? off : o[p][i];
+#else
                             const int hl = (o[p][i] >> 16) - 1, wl = (o[p][i] & 0xffff) - 1;
                             const bool use = (okm[p] >> i) & 1u;
                             const int off = use ? (T6_ZPX + basek + (hl - y0k) * wwk + (wl - x0k)) * 128 : 0;
                             o[p][i] = hotk ? off : o[p][i];
+#endif
                         }
                 }
                 T9_TICK(2)   // layout + offsets
                 // window DMA: the hot windows are ONE concatenated list of 8-pixel groups, group g belongs to wave g % TW of the team
                 if (!(T9_ABL & 4)) {
                     const float *vbn = value + ((size_t)cb * S * M + cm) * D;
+#if T9_DIET & 16
+                    const int n8 = uni(cum[4]) >> 3;                                   // groups of 8 pixels over all staged levels
+                    const int ga = (wt * n8) / TW, gb = ((wt + 1) * n8) / TW;           // this wave's run
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        const int c0 = uni(cum[l]) >> 3, c1 = uni(cum[l + 1]) >> 3;
+                        const int lo = max(ga, c0), hi = min(gb, c1);
+                        if (lo < hi) dma_level(l, hi - c0, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick, lo - c0);
+                    }
+#else
 #pragma unroll
                     for (int l = 0; l < 4; ++l) {
                         const int np = uni(cum[l + 1]) - uni(cum[l]);
                         if (np > 0) dma_level(l, np, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick, (uni(cum[l]) >> 3) % TW);
                     }
+#endif
                 }
                 T9_TICK(3)   // DMA issue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
@@ -598,7 +787,12 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 const bool has_late = uni(late_l) >= 0;   // (team-uniform)
                 if (has_late && !(T9_ABL & 4)) {          // its DMA goes out first and lands under pass 0 of the other levels
                     const float *vbc = value + ((size_t)cb * S * M + cm) * D;
+#if T9_DIET & 16
+                    const int n8l = uni(late_np) >> 3;
+                    dma_level(uni(late_l), ((wt + 1) * n8l) / TW, uni(late_base), vbc, magick_c, (wt * n8l) / TW);
+#else
                     dma_level(uni(late_l), uni(late_np), uni(late_base), vbc, magick_c, 0);
+#endif
                 }
                 // The passes in a ROLLED loop over ONE copy of the gather (two with the late form): the gather always reads the
                 // registers of pass 0, and behind a pass the next one's point data move there (20 moves; pass 0's are dead by then.
@@ -655,13 +849,7 @@ template <int WIN, bool PROF, bool EXACT>
 int t9_go(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B, int S,
           int M, int L, int Lq, float *out, uint16_t *out16, int hinted, hipStream_t st)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();   // (per device: a process-wide cache of the first device's count sized the grid wrongly on mixed hosts)
     constexpr size_t lds = (size_t)(T6_ZPX + WIN + T6_SLACK) * 128 + 256;
     static_assert(lds <= 163840, "LDS budget");
     static unsigned long long attr_mask = 0;

@@ -26,16 +26,17 @@ from . import _lib
 
 def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                   group, group_channels, offset_scale, im2col_step=256):
-    """input [N, H, W, group*group_channels], offset [N, Ho, Wo, group*kh*kw*2], mask [N, Ho, Wo, group*kh*kw] (fp32 or
-    fp64, contiguous, on the GPU) -> [N, Ho, Wo, group*group_channels].  ``im2col_step`` is checked as the reference
+    """input [N, H, W, group*group_channels], offset [N, Ho, Wo, group*kh*kw*2], mask [N, Ho, Wo, group*kh*kw] (fp16, fp32 or
+    fp64, contiguous, on the GPU; fp16: half operands, fp32 arithmetic, one rounding of the result) -> [N, Ho, Wo, group*group_channels].  ``im2col_step`` is checked as the reference
     does (batch must be divisible by min(batch, im2col_step), dcnv3_cuda.cu:46-49) and otherwise unused (one launch)."""
     for name, t in (("input", input), ("offset", offset), ("mask", mask)):
         if not t.is_cuda:
             raise RuntimeError("Not implement on cpu ({} must be a CUDA tensor)".format(name))
         if not t.is_contiguous():
             raise RuntimeError("{} tensor has to be contiguous".format(name))
-    if input.dtype not in (torch.float32, torch.float64) or offset.dtype != input.dtype or mask.dtype != input.dtype:
-        raise RuntimeError("dcnv3_forward: input, offset and mask must share dtype float32 or float64")
+    if input.dtype not in (torch.float16, torch.float32, torch.float64) or offset.dtype != input.dtype or mask.dtype != input.dtype:
+        raise RuntimeError("dcnv3_forward: input, offset and mask must share dtype float16, float32 or float64 "
+                           "(AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69)")
     N, H, W, C = input.shape
     if C != group * group_channels:
         raise RuntimeError("Input channels and group times group channels wont match: ({} vs {}).".format(
@@ -50,7 +51,7 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
         raise RuntimeError("dcnv3_forward: offset / mask do not match the output geometry [{}, {}, {}, .]".format(N, Ho, Wo))
     out = torch.empty((N, Ho, Wo, C), dtype=input.dtype, device=input.device)
     L = _lib.lib()
-    fn = L.vllm_dcnv3_forward_f32 if input.dtype == torch.float32 else L.vllm_dcnv3_forward_f64
+    fn = {torch.float16: L.vllm_dcnv3_forward_f16, torch.float32: L.vllm_dcnv3_forward_f32, torch.float64: L.vllm_dcnv3_forward_f64}[input.dtype]
     with torch.cuda.device(input.device):
         _lib.check(fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), N, H, W, group, group_channels, kernel_h, kernel_w,
                       stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, float(offset_scale), _lib.ptr(out),
@@ -67,8 +68,8 @@ def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, 
             raise RuntimeError("Not implement on cpu ({} must be a CUDA tensor)".format(name))
         if not t.is_contiguous():
             raise RuntimeError("{} tensor has to be contiguous".format(name))
-    if input.dtype not in (torch.float32, torch.float64) or any(t.dtype != input.dtype for t in (offset, mask, grad_output)):
-        raise RuntimeError("dcnv3_backward: input, offset, mask and grad_output must share dtype float32 or float64")
+    if input.dtype not in (torch.float16, torch.float32, torch.float64) or any(t.dtype != input.dtype for t in (offset, mask, grad_output)):
+        raise RuntimeError("dcnv3_backward: input, offset, mask and grad_output must share dtype float16, float32 or float64")
     N, H, W, C = input.shape
     if C != group * group_channels:
         raise RuntimeError("Input channels and group times group channels wont match: ({} vs {}).".format(
@@ -82,10 +83,25 @@ def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, 
     if tuple(offset.shape) != (N, Ho, Wo, group * P * 2) or tuple(mask.shape) != (N, Ho, Wo, group * P) or \
             tuple(grad_output.shape) != (N, Ho, Wo, C):
         raise RuntimeError("dcnv3_backward: offset / mask / grad_output do not match the output geometry [{}, {}, {}, .]".format(N, Ho, Wo))
+    L = _lib.lib()
+    if input.dtype == torch.float16:
+        # half operands, fp32 arithmetic on widened copies in a workspace this call owns, every gradient rounded once (the native
+        # entry point does the widening / zero fill / narrowing; dcnv3_cuda.cu:147 dispatches AND_HALF)
+        grad_input, grad_offset, grad_mask = torch.empty_like(input), torch.empty_like(offset), torch.empty_like(mask)
+        nbytes = L.vllm_dcnv3_backward_f16_workspace(N, H, W, group, group_channels, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                                     dilation_h, dilation_w)
+        if nbytes < 0:
+            raise RuntimeError("dcnv3_backward: invalid geometry")
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=input.device)
+        with torch.cuda.device(input.device):
+            _lib.check(L.vllm_dcnv3_backward_f16(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output), N, H, W, group,
+                                                 group_channels, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                                 float(offset_scale), _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask),
+                                                 _lib.ptr(ws), nbytes, _lib.current_stream(input.device)), "vllm_dcnv3_backward_f16")
+        return grad_input, grad_offset, grad_mask
     grad_input = torch.zeros_like(input)      # (the sums arrive by atomics: dcnv3_cuda.cu:118 zero-fills it as well)
     grad_offset = torch.empty_like(offset)
     grad_mask = torch.empty_like(mask)
-    L = _lib.lib()
     fn = L.vllm_dcnv3_backward_f32 if input.dtype == torch.float32 else L.vllm_dcnv3_backward_f64
     with torch.cuda.device(input.device):
         _lib.check(fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output), N, H, W, group, group_channels,
