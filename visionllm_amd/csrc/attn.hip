@@ -24,6 +24,11 @@
 
 namespace vllm {
 
+#ifndef ATT_EPI_DEFAULT     // 64: the automatic schedule stores O through LDS (round 5: ViT-L 82.0 -> 79.1 us, InternViT-6B 657 -> 628 us at 40 tiles,
+                            // bit-identical outputs, profiles/r05_attn_epilogue.txt); 0: straight from the accumulators (attn_variant 2)
+#define ATT_EPI_DEFAULT 64
+#endif
+
 // K/V staging.  The per-lane part of every source address (row-in-tile * token stride + swizzled 16-byte chunk) does not
 // change from tile to tile: it is computed ONCE (kv_lane_offsets) and each tile's LDS-DMA is then
 // (uniform tile base in SGPRs) + (that 32-bit lane offset) -> the saddr form of global_load_lds with a uniform LDS
@@ -81,7 +86,10 @@ __device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int 
 // bit2: s_setprio(1) around the MFMA clusters; bit3: V transpose-reads issued as inline asm BEFORE the softmax (the
 // compiler treats the tr-read builtin as 'may alias the LDS-DMA in flight' and puts s_waitcnt vmcnt(0) in front of it,
 // which drains the next tile's prefetch in the middle of every iteration).
-template <int D, int VAR, bool F16 = false>
+// EPI: 0 = every lane stores its 8-byte pieces straight from the accumulator layout (16 bytes per row and instruction: 32 partial
+// lines per store); 1 (round 5, the review's item 3-i / guide T21's LDS form) = the block's O tile goes through the (by then idle)
+// K/V ring and leaves as WHOLE ROWS, 16 bytes per lane, 8 (d = 64) or 4 (d = 128) full rows per instruction.
+template <int D, int VAR, bool F16 = false, int EPI = 0>
 __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void attn_fwd_kernel(const AttnArgs a)
 {
     constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0, ASMTR = (VAR & 8) != 0;
@@ -341,7 +349,35 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
     const float l_tot = halves_sum(l_run);
     const float inv = 1.0f / l_tot;
-    if (q_row < a.S) {
+    if constexpr (EPI == 1) {
+        // Rows through LDS.  The ring is dead once EVERY wave has left its last tile (one extra barrier per block); a wave then
+        // uses only ITS 32 rows x D x 2 bytes of it: no further synchronisation.  Row pitch D * 2 bytes (128 / 256: a multiple of
+        // the 256-byte bank span), so the 16-byte chunk index is XORed with the row (8 / 16 chunks per row): the 8-byte writes of a
+        // 16-lane group (16 rows, one chunk column) and the 16-byte reads (8 / 4 rows, every chunk) then spread over the banks.
+        constexpr int CPRO = D / 8;                   // 16-byte chunks per output row
+        __syncthreads();
+        char *wbase = smem + wave * (32 * D * 2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2_t w;
+                w.x = pack16x2<F16>(o[d][4 * rq] * inv, o[d][4 * rq + 1] * inv);
+                w.y = pack16x2<F16>(o[d][4 * rq + 2] * inv, o[d][4 * rq + 3] * inv);
+                const int chunk = d * 4 + rq;         // columns 8 * chunk .. + 7; this lane's half: 4 * hh
+                *reinterpret_cast<uint2_t *>(wbase + l31 * (D * 2) + ((chunk ^ (l31 & (CPRO - 1))) << 4) + hh * 8) = w;
+            }
+        // (same wave wrote what it reads: the LDS executes a wave's operations in order; the compiler's own lgkmcnt covers the data)
+        constexpr int RPI = 64 / CPRO;                // rows per store instruction
+        const int rr = lane / CPRO, cc = lane % CPRO;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + rr;
+            const uint4_t v = *reinterpret_cast<const uint4_t *>(wbase + row * (D * 2) + ((cc ^ (row & (CPRO - 1))) << 4));
+            const int qr = qt * QBLK + wave * 32 + row;
+            if (qr < a.S) *reinterpret_cast<uint4_t *>(a.out + (((long)b * a.S + qr) * a.H + head) * D + cc * 8) = v;
+        }
+    } else if (q_row < a.S) {
         uint16_t *orow = a.out + (((long)b * a.S + q_row) * a.H + head) * D;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -374,9 +410,21 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
     // attn_variant: 32 = automatic; bits 0-3 are attn_fwd_kernel's VAR, bit 4 switches the padding trim off.  (Schedule 2 -- the
     // hand-placed instruction stream of round 3, exactly as fast -- is tools/experiments/attn2.hip since round 4.)
     int var = attn_variant();
-    if (var & 32) var = 2;
+    if (var & 32) var = 2 | ATT_EPI_DEFAULT;
     a.no_trim = (var >> 4) & 1;
+    const bool epi_lds = (var >> 6) & 1;      // bit 6: O through LDS, whole-row stores (needs 16-byte aligned output rows)
     var &= 15;
+    if (epi_lds && var == 2 && aligned16(a.out)) {
+        if (a.f16) {
+            if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, true, 1>), grid, block, lds, st, a);
+            else VLLM_LAUNCH((attn_fwd_kernel<128, 2, true, 1>), grid, block, lds, st, a);
+        } else {
+            if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, false, 1>), grid, block, lds, st, a);
+            else VLLM_LAUNCH((attn_fwd_kernel<128, 2, false, 1>), grid, block, lds, st, a);
+        }
+        VLLM_CHECK_LAUNCH("attn_fwd_kernel");
+        return VLLM_OK;
+    }
 #define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
 #define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 2: LA(DD, 2); break; case 6: LA(DD, 6); break; \
     case 8: LA(DD, 8); break; case 10: LA(DD, 10); break; case 14: LA(DD, 14); break; case 3: LA(DD, 3); break; \
