@@ -318,7 +318,12 @@ int vllm_gemm_bf16_sk(const uint16_t *X, const uint16_t *W, const uint16_t *bias
  *     bf16), ln_colsum[n] = sum_k W'[n,k] (fp32; LayerNorm only), ln_bias[n] = b_n + sum_k beta_k W[n,k] (fp32, may be NULL; it
  *     replaces `bias`):  y = epilogue(r_m * (x W'^T) - r_m mean_m colsum_n + ln_bias_n),  r_m = rsqrt(var_m + ln_eps).
  * The row statistics are exact fp32 (the reference rounds the normalised tensor to bf16 first: the folded form differs from it
- * by that rounding, i.e. it is the more accurate of the two). */
+ * by that rounding, i.e. it is the more accurate of the two).
+ * Round 5, WIDE statistics (InternViT-6B, hidden 3200 = 12.5 column tiles): with ln_rms and ln_slots != 4 (1 .. 16; producer:
+ * ceil(N / 256), consumer: ceil(K / 256), N and K multiples of 8) the buffer is [M][16] floats, slot s = sum y^2 over column tile s,
+ * slots >= ln_slots ZERO (the caller clears the buffer once; the producer never writes them); the consumer adds all 16 in a fixed
+ * order.  Only the persistent schedule implements it (M, N large enough for at least one tile per CU): a call it does not take
+ * returns VLLM_EINVAL and the caller launches the norm instead (vllm_vit_forward asks with a dry run first). */
 int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uint16_t *bias, uint16_t *Y,
                       int M, int N, int K, int ldx, int ldw, int ldy, int epilogue,
                       const uint16_t *scale, const uint16_t *res, int ldr,
@@ -425,6 +430,8 @@ long vllm_vit_workspace_bytes(const VllmVitDesc *desc, int n_tiles);
 int vllm_vit_forward(const VllmVitDesc *desc, const void *pixels, int n_tiles,
                      uint16_t *const *hidden_states, void *workspace, long workspace_bytes,
                      vllm_stream_t stream);
+/* Cumulative number of GEMM launches of vllm_vit_forward that ran with a norm folded in (test hook: proves which path ran). */
+long vllm_vit_folded_gemm_launches(void);
 
 /* ------------------------------------------------------------------------------------------------
  * B2. Projector ("vl_bridge") with the hidden-state select / CLS drop / pixel-shuffle in front of it

@@ -128,7 +128,7 @@ def test_tiled_kernel_matches_gather_kernel(mode):
     try:
         plain = _run(g)
         ref = O.forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attw"])
-        for variant in (1, 18, 17, 3, 9):  # automatic (generation 9 on nested maps, else 4); 18: generation 8 (round 3's default); 17: generation 6 (the bf16 operator's kernel); 3: generation 2 (the > 32-bit-offset fallback); 9: generation 4 (any geometry).  Round 4: generation 7 and the alternative generation-4 configurations are out of the loop
+        for variant in (1, 17, 9):  # automatic (generation 9 on nested maps, else 4); 17: generation 6 (the bf16 operator's kernel, here on fp32 values); 9: generation 4 (any geometry).  Round 5: one kernel per geometry class -- generations 2 and 8 left the library (tools/experiments/)
             _lib.set_option("msda_tiled", variant)
             tiled = _run(g)
             again = _run(g)
@@ -178,7 +178,7 @@ def test_generation6_pyramid_items(name, mode):
     try:
         plain = _run(g)
         res = {}
-        for variant in (1, 18, 17):   # automatic = generation 9; 18 = generation 8 (two teams half a period apart); generation 7 (software pipeline across items); generation 6
+        for variant in (1, 17):   # automatic = generation 9; 17 = generation 6 (the bf16-value operator's kernel on fp32 values); generations 7 / 8 left the library (tools/experiments/)
             _lib.set_option("msda_tiled", variant)
             res[variant] = (_run(g), _run(g))
     finally:
@@ -248,7 +248,7 @@ def test_nan_and_inf_sampling_locations_contribute_nothing():
     flat[12::59] = -np.inf
     ref = O.forward(g["value"], g["shapes"], g["lsi"], loc, g["attw"])
     assert np.isfinite(ref).all()
-    for tiled in (0, 1, 17, 2, 3, 8, 9):
+    for tiled in (0, 1, 17, 2, 8, 9):   # (3 = generation 2 left the library in round 5)
         old = _lib.set_option("msda_tiled", tiled)
         try:
             out = A.ms_deform_attn_forward(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(loc), _t(g["attw"]), 64)

@@ -7,9 +7,9 @@ generation-9 race showed on 1 - 8 launches of 150 - 300 and only on location set
 two-run identity check passes that 98 % of the time, a hundred launches do not.  The reference's call sites swallow kernel errors
 (modeling_ov_grounding_dino_mask_dn.py:767-779), so a flaky kernel would be invisible downstream.
 
-The automatic choice is also compared bit-exactly against the previous generation (msda_tiled 18) where both apply: the two share every
-arithmetic step per (query, point), so a toolchain change that breaks generation 9's register assumptions shows as a difference
-(last item).  Whole file: ~30 s on MI355X.
+The automatic choice is also compared against the two kernels with plain, compiler-visible reads that serve the same shape (generation 4
+and the gather kernel; 2e-6: only the association of the weighted sum differs), so a toolchain change that breaks generation 9's
+register assumptions shows as a difference (last item; generation 8 left the library in round 5).  Whole file: ~30 s on MI355X.
 """
 import math
 
@@ -59,9 +59,8 @@ def test_msda_automatic_forward_100_launches_identical(name):
         for i in range(N_LAUNCH):
             out = _fwd(_dev(g))                     # fresh tensors every launch: new addresses, cold caches (as the tests do)
             assert torch.equal(out, first), f"{name}: launch {i} differs from the first (max {float((out - first).abs().max()):.3g})"
-        _lib.set_option("msda_tiled", 18)           # generation 8: same arithmetic per point, plain compiler-visible LDS reads
-        prev = _fwd(_dev(g))
-        torch.testing.assert_close(first, prev, rtol=2e-6, atol=2e-6)
+        _lib.set_option("msda_tiled", 9)            # generation 4 (any geometry): plain compiler-visible LDS reads, same arithmetic per point
+        torch.testing.assert_close(first, _fwd(_dev(g)), rtol=2e-6, atol=2e-6)
         _lib.set_option("msda_tiled", 0)            # gather kernel
         torch.testing.assert_close(first, _fwd(_dev(g)), rtol=2e-6, atol=2e-6)
     finally:

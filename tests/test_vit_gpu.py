@@ -768,7 +768,7 @@ def test_real_width_encoders_vs_oracle(arch):
     _check_states(out.hidden_states, ref, lo, arch)
 
 
-@pytest.mark.parametrize("arch", ["clip", "internvit"])
+@pytest.mark.parametrize("arch", ["clip", "internvit", "internvit_wide"])
 def test_folded_norms_agree_with_launched_norms(arch, monkeypatch):
     """Round 3: norm1 / norm2 folded into the GEMMs around them (the default at real widths) against the same model with the norms
     launched (descriptor without the prepared weights): the two differ by the bf16 rounding of the normalised tensor that the
@@ -781,6 +781,13 @@ def test_folded_norms_agree_with_launched_norms(arch, monkeypatch):
                     image_size=336, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5)
         make = lambda: CLIPVisionModel(CLIPVisionConfig(**cfgd))  # noqa: E731
         n, mod = 2, CV
+    elif arch == "internvit_wide":
+        # round 5: InternViT-6B's width (hidden 3200 = 12.5 column tiles: the WIDE statistics layout, a ragged last tile in the
+        # producer), two layers, 5 tiles of 448^2 = 5125 rows -- the smallest batch whose four GEMMs all take the persistent schedule
+        cfgd = dict(hidden_size=3200, num_attention_heads=25, intermediate_size=12800, num_hidden_layers=2,
+                    image_size=448, patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu", layer_norm_eps=1e-6)
+        make = lambda: InternVisionModel(InternVisionConfig(**cfgd))  # noqa: E731
+        n, mod = 5, IV
     else:
         cfgd = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=3,
                     image_size=448, patch_size=14, qk_normalization=True, qkv_bias=False, hidden_act="gelu", layer_norm_eps=1e-6)
@@ -800,11 +807,17 @@ def test_folded_norms_agree_with_launched_norms(arch, monkeypatch):
     sd = model.state_dict()
     x = bf(torch.randn(n, 3, cfgd["image_size"], cfgd["image_size"])).to(DEV)
     model = model.to(DEV).to(torch.bfloat16)
+    from visionllm_amd import _lib
+    n0 = _lib.lib().vllm_vit_folded_gemm_launches()
     folded = model(x, output_hidden_states=True).hidden_states
-    again = model(x, output_hidden_states=True).hidden_states
-    assert all(torch.equal(a, b) for a, b in zip(folded, again))
+    n_folded = _lib.lib().vllm_vit_folded_gemm_launches() - n0
+    # every layer: proj (producer) + fc1 (consumer); fc2 / qkv between consecutive layers
+    assert n_folded == 2 * cfgd["num_hidden_layers"] + 2 * (cfgd["num_hidden_layers"] - 1), f"{n_folded} GEMM launches ran with a folded norm"
+    for _ in range(3 if arch == "internvit_wide" else 1):     # (the wide producer is a new register-tight instantiation: a few more identical runs)
+        again = model(x, output_hidden_states=True).hidden_states
+        assert all(torch.equal(a, b) for a, b in zip(folded, again))
     assert any(int(getattr(l, "qkv_w_ln") or 0) != 0 for l in model._plan.layers), "the folded path was expected to be prepared"
-    monkeypatch.setattr(mod, "norm_folding_applies", lambda *a: False)
+    monkeypatch.setattr(mod, "norm_folding_applies", lambda *a, **k: False)
     plain_model = make()
     plain_model.load_state_dict(sd)
     plain_model = plain_model.to(DEV).to(torch.bfloat16)

@@ -27,7 +27,7 @@ def lib_mode(m):
         _lib.set_option("msda_tiled", m)
         A.ms_deform_attn_forward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], 64)
     return f
-fns["lib_gen8"] = lib_mode(18); fns["lib_gen9"] = lib_mode(20)
+fns["lib_gen9"] = lib_mode(20)   # (generation 8 left the library in round 5: tools/experiments/msda_tiled8.hip)
 for name, f in fns.items():
     if name.startswith("abl") or name.startswith("lib"): continue
     out.zero_(); f(); torch.cuda.synchronize()

@@ -29,7 +29,7 @@ def timeit(iters=10):
         run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-modes = {"automatic_gen9": 1, "gen8": 18, "gather": 0}
+modes = {"automatic_gen9": 1, "gen4_any_geometry": 9, "gather": 0}
 for _ in range(2):
     for k, v in modes.items():
         _lib.set_option("msda_tiled", v); timeit(3)

@@ -342,6 +342,8 @@ extern "C" int vllm_gemm_bf16_ln(const uint16_t *X, const uint16_t *W, const uin
     if (epilogue & 0x1000) a.no_persist = 1;
     a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ln_slots; a.ln_cols = K; a.ln_rms = ln_rms; a.ln_eps = ln_eps;
     a.ln_colsum = ln_colsum; a.ln_bias = ln_bias;
+    // round 5: RMSNorm rows of a hidden size other than four column tiles use the WIDE statistics layout ([M][16] floats, header)
+    a.ln_wide = (ln_rms && ln_slots != 4 && ln_slots >= 1 && ln_slots <= 16) ? 1 : 0;
     return gemm_bf16_launch(epilogue & 0xff, a, (hipStream_t)stream);
 }
 

@@ -781,12 +781,16 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
     if (a.ln_in || a.ln_out) {   // folded norm: the row-wise LDS epilogue is where it lives
         VLLM_REQUIRE(epi != EPI_F32 && (a.N & 7) == 0 && (a.ldy & 7) == 0 && aligned16(a.Y) && a.variant256 != 5,
                      "gemm256: a folded norm needs the bf16 row-wise epilogue (N, ldy multiples of 8, 16-byte aligned Y, not the 32x32x16 variant)");
-        VLLM_REQUIRE(!a.ln_in || (a.ln_slots == 4 && aligned16(a.ln_in) && a.ln_cols == a.K && (a.ln_rms || a.ln_colsum) &&
+        VLLM_REQUIRE(!a.ln_wide || (a.ln_rms && (!a.ln_in || (a.ln_slots >= 1 && a.ln_slots <= 16 && a.ln_cols == a.K && aligned16(a.ln_in) &&
+                                                              (!a.ln_bias || aligned16(a.ln_bias)) && (a.N & 3) == 0))),
+                     "gemm256: wide folded-norm statistics are RMSNorm sums of squares in at most 16 column tiles per row");
+        VLLM_REQUIRE(a.ln_wide || !a.ln_in || (a.ln_slots == 4 && aligned16(a.ln_in) && a.ln_cols == a.K && (a.ln_rms || a.ln_colsum) &&
                                   (!a.ln_colsum || aligned16(a.ln_colsum)) && (!a.ln_bias || aligned16(a.ln_bias)) && (a.N & 3) == 0),
                      "gemm256: folded norm, consumer: statistics of K-element rows in FOUR column tiles (768 < K <= 1024), column sums (LayerNorm), 16-byte aligned fp32 vectors");
         VLLM_REQUIRE(!a.ln_out || (reinterpret_cast<uintptr_t>(a.ln_out) & 7u) == 0, "gemm256: folded norm, producer: misaligned statistics buffer");
         a.direct_store = 0;
-        if (a.ln_in) {
+        if (a.ln_in && a.ln_wide) a.ln_inv_cols = 1.f / (float)a.ln_cols;
+        else if (a.ln_in) {
             float cnt = 0.f;
             for (int sidx = 0; sidx < 4; ++sidx) {
                 const float nb = (float)std::min(G2_BN, a.ln_cols - sidx * G2_BN), tot = cnt + nb;
@@ -875,8 +879,11 @@ int gemm256_bf16_launch(int epi, GemmArgs a, hipStream_t st)
         GemmArgs b = a;
         b.sk_tiles = 0;
         b.mt = ceil_div(a.M, 64 * pmt);
-        if (gemm256p_takes(epi, b, cus)) return gemm256p_launch(epi, pmt, b, cus, st);
+        if (gemm256p_takes(epi, b, cus)) return a.dry_run ? VLLM_OK : gemm256p_launch(epi, pmt, b, cus, st);
     }
+    if (a.dry_run) return VLLM_EINVAL;   // (asked only whether the persistent schedule would take this GEMM: no message, no launch)
+    VLLM_REQUIRE(!a.ln_wide, "gemm256: wide folded-norm statistics are implemented by the persistent schedule only (at least as many tiles as CUs, "
+                             "aligned operands); the caller launches the norm instead for this shape");
     long tiles;
     if (a.sk_tiles > 0) {
         ++g_sk_launches;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void store_piece(u32x4_t &o, __amdgpu_buffer_rsrc_t r
 // HALFT: the instantiation that can run the last round as half-height tiles (see the tile loop).  A separate instantiation because
 // the second K loop costs the whole-tile loop registers (210 -> 237 VGPRs, 4 -> 33 spilled SGPRs) and 2 % of its speed (fc1, same box:
 // 169 -> 173 us): launches whose last round stays whole keep the kernel they had.
-template <int EPI, int MT, bool LNC, bool STATS = false, bool HALFT = false>
+template <int EPI, int MT, bool LNC, int STATS = 0, bool HALFT = false>   // STATS: 0 none, 1 {mean, M2} pairs per (row, tile), 2 wide (RMSNorm: one float per (row, tile), ragged last tile allowed)
 __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a)
 {
     static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_QUICK_GELU || (EPI == EPI_RESIDUAL && !LNC),
@@ -194,8 +194,12 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
     };
     // the column vectors (and, folded norm, the row statistics) of the tile at (mm, nn) into buffer `buf`: waves 0-1 / 0-7
     auto issue_vectors = [&](int mm, int nn, int buf) {
+        // (the lane number is re-derived here, two VALU: as a value carried across the main loop it -- and the clamped column offset
+        //  computed from it -- were what the register allocator spilled in the residual instantiations)
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         if constexpr (LNC) {
-            {   // wave w: rows 32 w .. 32 w + 31 of the tile, two lanes per row (16 of its 32 bytes each)
+            if (!a.ln_wide) {   // wave w: rows 32 w .. 32 w + 31 of the tile, two lanes per row (16 of its 32 bytes each)
                 int row = mm + wave * 32 + (lane >> 1);
                 row = row < a.M ? row : a.M - 1;
                 const float *src = a.ln_in + (size_t)row * 8 + (lane & 1) * 4;
@@ -221,6 +225,22 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                 c8 = c8 + 8 <= a.N ? c8 : a.N - 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.scale + c8),
                                                  (__attribute__((address_space(3))) void *)(smem + P_COL + buf * 2048 + 1024), 16, 0, 0);
+            }
+        }
+    };
+    // Wide statistics (round 5; GemmArgs::ln_wide: RMSNorm rows of up to 16 column tiles, 16 floats = 64 bytes per row): the 256 rows
+    // of a tile are 16 KiB -- the whole raw region, ONE buffer: a tile's statistics are requested only after the previous tile's row
+    // table has been built from it (they are needed a whole main loop later).  Wave w: rows 32 w .. 32 w + 31, four lanes per row,
+    // two instructions.
+    auto issue_stats_wide = [&](int mm) {
+        if constexpr (LNC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int row = mm + wave * 32 + i * 16 + (lane >> 2);
+                row = row < a.M ? row : a.M - 1;
+                const float *src = a.ln_in + (size_t)row * 16 + (lane & 3) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + P_RAW + (wave * 2 + i) * 1024), 16, 0, 0);
             }
         }
     };
@@ -317,6 +337,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
     for (int i = tid; i < (P_LDS - P_RING) / 4; i += P_THREADS) reinterpret_cast<unsigned *>(smem + P_RING)[i] = 0u;   // (missing vectors read as zeros)
     __syncthreads();
     issue_vectors(m0, n0, 0);
+    if (LNC && a.ln_wide) issue_stats_wide(m0);
     issue_A(0, 0, 0); issue_B(0, 0, 0); issue_B(1, 0, 0); issue_A(1, 0, 0);
     issue_A(0, 1, 1); issue_B(1, 1, 1); issue_A(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -428,6 +449,19 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
         if constexpr (LNC) {
             // the row table {r, -r mean} of this tile from its statistics (Chan's update in a fixed order, constants from the
             // launcher)
+            if (a.ln_wide) {
+                if (tid < BM) {   // 16 slots of row tid (unused ones are zero: cleared once per call by the orchestrator), a fixed tree
+                    f32x4_t w0, w1, w2, w3;
+                    const unsigned addr = (unsigned)(size_t)(smem + P_RAW + tid * 64);
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(addr) : "memory");
+                    const float ss = (((w0[0] + w0[1]) + (w0[2] + w0[3])) + ((w1[0] + w1[1]) + (w1[2] + w1[3]))) +
+                                     (((w2[0] + w2[1]) + (w2[2] + w2[3])) + ((w3[0] + w3[1]) + (w3[2] + w3[3])));
+                    reinterpret_cast<float2_t *>(smem + P_TAB)[tid] = (float2_t){__builtin_amdgcn_rsqf(fmaf(ss, a.ln_inv_cols, a.ln_eps)), 0.f};
+                }
+                P_WAIT_LGKM0(); P_BARRIER();
+                if (more) issue_stats_wide(m0n);   // (the raw region is free again: every reader is behind the barrier)
+            } else {
             if (tid < BM) {
                 // (read with inline ds_read: for a compiler-visible LDS load behind an LDS-DMA the compiler drains vmcnt to 0 --
                 //  here that would wait for the next tile's refills; the statistics landed a whole main loop ago)
@@ -457,6 +491,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                 reinterpret_cast<float2_t *>(smem + P_TAB)[tid] = (float2_t){r_, nrm_};
             }
             P_WAIT_LGKM0(); P_BARRIER();
+            }
         }
         if constexpr (RES) {
             // ---- residual epilogue: y = res + (acc + bias) * LayerScale, one rounding.  The lane-row exchange is done on the fp32
@@ -471,6 +506,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
             u32x4_t o_prev = {0u, 0u, 0u, 0u};
             unsigned so_prev = 0u, yv_prev = 0u;
             unsigned yv[2];
+            const bool rms_ = STATS == 2 ? true : (a.ln_rms != 0);   // (wide statistics exist for RMSNorm only: a constant there)
             float st_m[STATS ? MT : 1], st_q[STATS ? MT : 1];   // a lane's {mean, M2} of the qj = 0 pieces, until their qj = 1 partners
 #pragma unroll
             for (int qj = 0; qj < 2; ++qj) yv[qj] = n0 + qj * 128 + ycol + 8 <= a.N ? yvo : 0x80000000u;
@@ -519,10 +555,11 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
 #pragma unroll
                         for (int k2 = 0; k2 < 4; ++k2) { x_[2 * k2] = bf16lo_to_f32(u[k2]); x_[2 * k2 + 1] = bf16hi_to_f32(u[k2]); }
                         float pm, pq = 0.f;
-                        if (a.ln_rms) {
+                        if (rms_) {
                             pm = 0.f;
 #pragma unroll
                             for (int k2 = 0; k2 < 8; ++k2) pm = fmaf(x_[k2], x_[k2], pm);
+                            if constexpr (STATS == 2) { if (yv[qj] == 0x80000000u) pm = 0.f; }   // (ragged last column tile: columns beyond N do not exist)
                         } else {
                             pm = ((x_[0] + x_[1]) + (x_[2] + x_[3])) + ((x_[4] + x_[5]) + (x_[6] + x_[7]));
                             pm *= 0.125f;
@@ -532,10 +569,10 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                         if (qj == 0) { st_m[j] = pm; st_q[j] = pq; }
                         else {
                             float mean = st_m[j], m2 = st_q[j];
-                            if (a.ln_rms) mean += pm;
+                            if (rms_) mean += pm;
                             else { const float d = pm - mean; mean = fmaf(0.5f, d, mean); m2 = fmaf(d * d, 4.f, m2 + pq); }
-                            pair_combine<16>(mean, m2, 8.f, a.ln_rms != 0);
-                            pair_combine<32>(mean, m2, 16.f, a.ln_rms != 0);
+                            pair_combine<16>(mean, m2, 8.f, rms_);
+                            pair_combine<32>(mean, m2, 16.f, rms_);
                             if (kq == 0) reinterpret_cast<float2_t *>(smem + P_RAW)[(qi * HM + wr * (16 * MT) + j * 16 + fr) * 4 + wc] = (float2_t){mean, m2};
                         }
                     }
@@ -554,7 +591,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                                      : "=&v"(pp[0]), "=&v"(pp[1]), "=&v"(pp[2]), "=&v"(pp[3]) : "v"(addr) : "memory");
                     }
                     float2_t r_;
-                    if (a.ln_rms) r_ = (float2_t){(pp[0].x + pp[1].x) + (pp[2].x + pp[3].x), 0.f};
+                    if (rms_) r_ = (float2_t){(pp[0].x + pp[1].x) + (pp[2].x + pp[3].x), 0.f};
                     else {
                         const float d0 = pp[1].x - pp[0].x, d1 = pp[3].x - pp[2].x;
                         const float m0_ = fmaf(0.5f, d0, pp[0].x), m1_ = fmaf(0.5f, d1, pp[2].x);
@@ -563,7 +600,9 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm256p_kernel(const GemmArgs a
                         r_ = (float2_t){fmaf(0.5f, d, m0_), fmaf(d * d, 64.f, q0_ + q1_)};
                     }
                     const int m = m0 + tid;
-                    if (m < a.M) *reinterpret_cast<float2_t *>(a.ln_out + ((size_t)m * a.nt + (n0 >> 8)) * 2) = r_;
+                    if constexpr (STATS == 2) {   // (slots >= nt of a row are never written: the orchestrator clears the buffer once per call)
+                        if (m < a.M) a.ln_out[(size_t)m * 16 + (n0 >> 8)] = r_.x;
+                    } else if (m < a.M) *reinterpret_cast<float2_t *>(a.ln_out + ((size_t)m * a.nt + (n0 >> 8)) * 2) = r_;
                 }
             }
         } else
@@ -662,7 +701,9 @@ bool gemm256p_takes(int epi, const GemmArgs &a, int cus)
     if (persist_disabled() || a.no_persist || (cus & 7) != 0) return false;
     if (!(epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_QUICK_GELU || epi == EPI_RESIDUAL)) return false;
     if (a.xP != 0 || a.sk_tiles > 0 || a.variant256 == 5) return false;
-    if (a.ln_out && (epi != EPI_RESIDUAL || (a.N % P_BN) != 0 || (reinterpret_cast<uintptr_t>(a.ln_out) & 7u) != 0)) return false;
+    if (a.ln_out && (epi != EPI_RESIDUAL || ((a.N % P_BN) != 0 && !a.ln_wide) || (reinterpret_cast<uintptr_t>(a.ln_out) & 7u) != 0)) return false;
+    if (a.ln_wide && ((a.ln_in && (!a.ln_rms || a.ln_slots > 16 || (reinterpret_cast<uintptr_t>(a.ln_in) & 15u) != 0)) ||
+                      (a.ln_out && (!a.ln_rms || (a.N + P_BN - 1) / P_BN > 16 || (a.N & 7) != 0)))) return false;
     if ((a.N & 7) != 0 || a.N < P_BN || (a.K % P_BK) != 0 || a.K < 2 * P_BK || (a.ldy & 3) != 0 || (a.ldx & 7) != 0 || (a.ldw & 7) != 0) return false;
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!al16(a.X) || !al16(a.W) || !al16(a.Y) || (a.bias && !al16(a.bias))) return false;
@@ -714,22 +755,27 @@ int gemm256p_launch(int epi, int MT, const GemmArgs &a_, int cus, hipStream_t st
 #define SETATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 4, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
                       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E, 3, L>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
                       if (E != EPI_RESIDUAL) { \
-                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 4, L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
-                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 3, L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); }
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 4, L, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<E == EPI_RESIDUAL ? EPI_BIAS : E, 3, L, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); }
         SETATTR(EPI_BIAS, false); SETATTR(EPI_GELU, false); SETATTR(EPI_QUICK_GELU, false);
         SETATTR(EPI_BIAS, true); SETATTR(EPI_GELU, true); SETATTR(EPI_QUICK_GELU, true); SETATTR(EPI_RESIDUAL, false);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 4, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 3, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256p_kernel<EPI_RESIDUAL, 3, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
 #undef SETATTR
     }
-#define LAUNCH_H(E, H) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true, false, H>), grid, block, P_LDS, st, a); \
-                                            else VLLM_LAUNCH((gemm256p_kernel<E, 3, true, false, H>), grid, block, P_LDS, st, a); } \
-                            else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false, false, H>), grid, block, P_LDS, st, a); \
-                                   else VLLM_LAUNCH((gemm256p_kernel<E, 3, false, false, H>), grid, block, P_LDS, st, a); } } while (0)
+#define LAUNCH_H(E, H) do { if (a.ln_in) { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, true, 0, H>), grid, block, P_LDS, st, a); \
+                                            else VLLM_LAUNCH((gemm256p_kernel<E, 3, true, 0, H>), grid, block, P_LDS, st, a); } \
+                            else { if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<E, 4, false, 0, H>), grid, block, P_LDS, st, a); \
+                                   else VLLM_LAUNCH((gemm256p_kernel<E, 3, false, 0, H>), grid, block, P_LDS, st, a); } } while (0)
 #define LAUNCH(E) do { if (a.half_tail) LAUNCH_H(E, true); else LAUNCH_H(E, false); } while (0)
-    if (epi == EPI_RESIDUAL && a.ln_out) {
-        if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false, true>), grid, block, P_LDS, st, a);
-        else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false, true>), grid, block, P_LDS, st, a);
+    if (epi == EPI_RESIDUAL && a.ln_out && a.ln_wide) {
+        if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false, 2>), grid, block, P_LDS, st, a);
+        else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false, 2>), grid, block, P_LDS, st, a);
+    } else if (epi == EPI_RESIDUAL && a.ln_out) {
+        if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false, 1>), grid, block, P_LDS, st, a);
+        else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false, 1>), grid, block, P_LDS, st, a);
     } else if (epi == EPI_RESIDUAL) {
         if (MT == 4) VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 4, false>), grid, block, P_LDS, st, a);
         else VLLM_LAUNCH((gemm256p_kernel<EPI_RESIDUAL, 3, false>), grid, block, P_LDS, st, a);

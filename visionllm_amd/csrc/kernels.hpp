@@ -58,6 +58,9 @@ struct GemmArgs {
     int ln_slots = 0;               // column tiles per row of ln_in
     int ln_cols = 0;                // elements per normalised row (the producer's N)
     int ln_rms = 0;                 // 1: RMSNorm (second moment about zero, no shift)
+    int dry_run = 0;                // 1: gemm256_bf16_launch only answers whether the persistent schedule would take the call (VLLM_OK) or not
+    int ln_wide = 0;                // 1 (round 5, RMSNorm only, the persistent kernel only): statistics as [M][16] floats -- slot s = sum of squares of
+                                    //    column tile s, unused slots 0 -- for rows of up to 16 column tiles (hidden 3200: 13); 0: [M][nt][2], four tiles
     float ln_eps = 0.f;
     const float *ln_colsum = nullptr;   // consumer: s_n = sum_k W'[n, k] (LayerNorm), fp32 [N]
     const float *ln_bias = nullptr;     // consumer: bias'_n = b_n + sum_k beta_k W[n, k] (fp32 [N]; NULL = 0); replaces `bias`

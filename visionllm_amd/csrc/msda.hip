@@ -29,7 +29,7 @@
 
 namespace vllm {
 
-bool msda_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *out, const void *loc);
+bool msda_tiled_ok(int D, int L, int P, int Lq, int S, int B, int M, const void *value, const void *out, const void *loc);
 int msda_tiled_enabled();   // runtime.cpp
 bool msda_tiled6_ok(int D, int L, int P, int Lq, int S, int B, int M);   // msda_tiled6.hip
 int msda_tiled6_launch_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
@@ -509,7 +509,7 @@ int msda_forward_f32_out16(const float *value, const int64_t *shapes, const int6
 {
     *where = 0;
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
-    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc) && (reinterpret_cast<uintptr_t>(out16) & 7u) == 0)
+    if (msda_tiled_ok(D, L, P, Lq, S, B, M, value, out, loc) && (reinterpret_cast<uintptr_t>(out16) & 7u) == 0)
         return msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, out16, where, geometry);
     return vllm_msda_forward_f32(value, shapes, lsi, loc, attw, B, S, M, D, L, Lq, P, out, (vllm_stream_t)st);
 }
@@ -533,7 +533,7 @@ extern "C" int vllm_msda_forward_f32_geo(const float *value, const int64_t *shap
     VLLM_REQUIRE(value && shapes && lsi && loc && attw && out, "msda_forward_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (msda_tiled_ok(D, L, P, Lq, S, value, out, loc)) {   // encoder self-attention shape: LDS-tiled kernel
+    if (msda_tiled_ok(D, L, P, Lq, S, B, M, value, out, loc)) {   // encoder self-attention shape: LDS-tiled kernel
         prof_mark(PT_MSDA_ENC, st);
         rc = msda_tiled_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, P, out, st, nullptr, nullptr, geometry);
     } else {

@@ -110,7 +110,7 @@ extern "C" int vllm_set_option(const char *name, int value)
     vllm::set_error("unknown option %s", name);
     return VLLM_EINVAL;
 }
-namespace vllm { int dcnv3_pipe_debug_counters(long *out, int n); int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda8_debug_counters(long *out, int n); int msda9_debug_counters(long *out, int n); }
+namespace vllm { int dcnv3_pipe_debug_counters(long *out, int n); int gemm256_debug_counters(long *out, int n); int dcnv3_debug_counters(long *out, int n); int msda_debug_counters(long *out, int n); int msda6_debug_counters(long *out, int n); int msda9_debug_counters(long *out, int n); }
 extern "C" int vllm_debug_counters(long *out, int n)
 {
     if (!out || n <= 0) { vllm::set_error("vllm_debug_counters: bad arguments"); return VLLM_EINVAL; }
@@ -118,7 +118,7 @@ extern "C" int vllm_debug_counters(long *out, int n)
     if (vllm::dcnv3_tiled_enabled() == 2) return vllm::dcnv3_pipe_debug_counters(out, n);
     if (vllm::dcnv3_tiled_enabled() == 4) return vllm::dcnv3_debug_counters(out, n);
     const int mode = vllm::msda_tiled_enabled();
-    return mode >= 20 ? vllm::msda9_debug_counters(out, n) : mode >= 18 ? vllm::msda8_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
+    return mode >= 20 ? vllm::msda9_debug_counters(out, n) : mode >= 10 ? vllm::msda6_debug_counters(out, n) : vllm::msda_debug_counters(out, n);
 }
 // ---- in-step kernel timing ----------------------------------------------------------------------------------------
 #include <vector>

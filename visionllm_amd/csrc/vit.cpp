@@ -5,6 +5,7 @@
 // (VisionLLMv2/visionllmv2/model/internvit/modeling_intern_vit.py:253-270) and of HF CLIPEncoder;
 // vllm_bridge_forward replaces select + pixel_shuffle + vl_bridge (visionllmv2/model/modeling_visionllmv2.py:569-579).
 #include <stdlib.h>
+#include <algorithm>
 #include "kernels.hpp"
 
 using namespace vllm;
@@ -31,7 +32,7 @@ VitWs vit_ws_layout(const VllmVitDesc *d, int n)
     w.h0 = take(M * d->hidden * 2);   // ping-pong hidden states for entries the caller does not want
     w.h1 = take(M * d->hidden * 2);
     w.sk = take(SK_SCRATCH_BYTES);    // stream-K tail of the GEMMs (kernels.hpp)
-    w.ln = take(2 * M * ((d->hidden + 255) / 256) * 2 * 4);   // folded norms: {mean, M2} per (row, 256-column tile), two buffers
+    w.ln = take(2 * M * std::max((d->hidden + 255) / 256 * 2, 16) * 4);   // folded norms: {mean, M2} per (row, 256-column tile) or the wide layout's 16 floats per row; two buffers
     w.total = off;
     return w;
 }
@@ -64,6 +65,9 @@ extern "C" long vllm_vit_workspace_bytes(const VllmVitDesc *d, int n_tiles)
 }
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != VLLM_OK) return rc__; } while (0)
+
+static long g_folded_gemms = 0;   // GEMM launches with a norm folded in (tests assert the path they mean to cover ran)
+extern "C" long vllm_vit_folded_gemm_launches(void) { return __atomic_load_n(&g_folded_gemms, __ATOMIC_RELAXED); }
 
 extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n, uint16_t *const *hs, void *workspace,
                                 long ws_bytes, vllm_stream_t stream)
@@ -111,9 +115,15 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
     // descriptor and shapes that take the 8-phase GEMM; VLLM_LN_FOLD=0 switches it off (A/B).
     static const int fold_off = [] { const char *e = getenv("VLLM_LN_FOLD"); return e && e[0] == '0' ? 1 : 0; }();
     const int ntC = (C + 255) / 256;
-    float *ln_a = (float *)(ws + w.ln), *ln_b = ln_a + (size_t)M * ntC * 2;
-    // (the consumer stages the statistics of rows of exactly four 256-column tiles: hidden size 1024 -- ViT-L, InternViT-300M)
-    const bool shapes_fold = !fold_off && M >= 1024 && C == 1024 && I >= 1024 && I % 8 == 0;
+    // (two buffers; the wide layout is 16 floats per row whatever ntC -- M * 16 <= M * ntC * 2 floats for ntC >= 8 -- and keeps ln_b 16-byte aligned for odd M)
+    float *ln_a = (float *)(ws + w.ln), *ln_b = ln_a + (size_t)M * ((d->arch != VLLM_ARCH_CLIP && C != 1024) ? 16 : ntC * 2);
+    // (the consumer stages the statistics of rows of exactly four 256-column tiles: hidden size 1024 -- ViT-L, InternViT-300M.
+    //  Round 5: RMSNorm rows of up to 16 column tiles -- InternViT-6B, hidden 3200 = 12.5 tiles -- in the WIDE format, one float per
+    //  (row, tile), which only the persistent GEMM schedule implements: the fold is on when all four GEMMs of a layer take that
+    //  schedule at this batch size (asked below with a dry run), otherwise the norms are launched as before.)
+    const bool wide = !clip && C != 1024;
+    bool shapes_fold = !fold_off && M >= 1024 && I >= 1024 && I % 8 == 0 && (C == 1024 || (wide && C % 8 == 0 && ntC <= 16));
+    int dry = 0;
     auto gemm_ln = [&](int epi, const uint16_t *X, int ldx, const uint16_t *W, int ldw, const uint16_t *bias, uint16_t *Y, int ldy, int N,
                        int K, const uint16_t *scale, const uint16_t *res, int ldr, float *ln_out, const float *ln_in,
                        const float *colsum, const float *bias_ln) {
@@ -124,9 +134,28 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
         a.variant = gemm_variant_override(); a.variant256 = 0; a.direct_store = gemm_direct_store();
         if (a.variant == 1 || a.variant == 4) a.variant = 0;   // (a forced 128x128 kernel / the 32x32x16 variant cannot fold)
         a.ln_out = ln_out; a.ln_in = ln_in; a.ln_slots = ntC; a.ln_cols = C; a.ln_rms = clip ? 0 : 1; a.ln_eps = d->eps;
-        a.ln_colsum = colsum; a.ln_bias = bias_ln;
+        a.ln_colsum = colsum; a.ln_bias = bias_ln; a.ln_wide = wide ? 1 : 0; a.dry_run = dry;
+        if (!dry) __atomic_fetch_add(&g_folded_gemms, 1L, __ATOMIC_RELAXED);
         return gemm_bf16_launch(epi, a, st);
     };
+    if (shapes_fold && wide && d->num_layers > 0) {
+        // dry run of the four folded GEMMs of a layer with layer 0's operands (shapes and alignments are the same in every layer)
+        const VllmVitLayer &L0 = d->layers[0];
+        if (L0.qkv_w_ln && L0.fc1_w_ln && L0.proj_w && L0.fc2_w) {
+            dry = 1;
+            const bool ok = gemm_ln(EPI_BIAS, hmid, C, L0.qkv_w_ln, C, nullptr, qkv, 3 * C, 3 * C, C, nullptr, nullptr, 0, nullptr, ln_a, nullptr, L0.qkv_bias_ln) == VLLM_OK &&
+                            gemm_ln(EPI_RESIDUAL, ao, C, L0.proj_w, C, L0.proj_b, hmid, C, C, C, L0.ls1, hmid, C, ln_b, nullptr, nullptr, nullptr) == VLLM_OK &&
+                            gemm_ln(d->act, hmid, C, L0.fc1_w_ln, C, nullptr, mid, I, I, C, nullptr, nullptr, 0, nullptr, ln_b, nullptr, L0.fc1_bias_ln) == VLLM_OK &&
+                            gemm_ln(EPI_RESIDUAL, mid, I, L0.fc2_w, I, L0.fc2_b, hmid, C, C, I, L0.ls2, hmid, C, ln_a, nullptr, nullptr, nullptr) == VLLM_OK;
+            dry = 0;
+            if (getenv("VLLM_VIT_DEBUG")) fprintf(stderr, "vit: wide norm fold dry run at M=%ld C=%d I=%d: %s (%s)\n", (long)M, C, I, ok ? "taken" : "refused", vllm_last_error());
+            if (!ok) shapes_fold = false;
+        } else shapes_fold = false;
+        if (shapes_fold && hipMemsetAsync(ln_a, 0, (size_t)2 * M * 16 * sizeof(float), st) != hipSuccess) {   // (the wide layout's unused slots are read as zeros)
+            set_error("vit: hipMemsetAsync of the folded-norm statistics failed");
+            return VLLM_ELAUNCH;
+        }
+    }
     auto folds = [&](int i) {   // layer i has the prepared weights
         return shapes_fold && i >= 0 && i < d->num_layers && d->layers[i].qkv_w_ln && d->layers[i].fc1_w_ln &&
                (!clip || (d->layers[i].qkv_colsum && d->layers[i].fc1_colsum));

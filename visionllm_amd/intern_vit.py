@@ -190,7 +190,7 @@ class InternVisionModel(nn.Module):
         for i, lyr in enumerate(self.encoder.layers):
             a = lyr.attn
             fold = {}
-            if norm_folding_applies(cfg.hidden_size, cfg.intermediate_size):
+            if norm_folding_applies(cfg.hidden_size, cfg.intermediate_size, rms=True):
                 q_ln, _, q_b = fold_norm_into_linear(a.qkv.weight, a.qkv.bias, lyr.norm1.weight, None, False)
                 f_ln, _, f_b = fold_norm_into_linear(lyr.mlp.fc1.weight, lyr.mlp.fc1.bias, lyr.norm2.weight, None, False)
                 plan.keep += [q_ln, q_b, f_ln, f_b]

@@ -54,12 +54,17 @@ def fold_norm_into_linear(w, b, gamma, beta, layernorm):
     return w_ln, colsum, (bias_ln.contiguous() if bias_ln is not None else None)
 
 
-def norm_folding_applies(hidden_size, intermediate_size):
-    """The encoder folds its norms into the GEMMs around them at hidden size 1024 (ViT-L, InternViT-300M: rows of exactly four
-    256-column tiles, what the consumer GEMM stages; the C side also asks for >= 1024 tokens per call); VLLM_LN_FOLD=0 keeps the
-    norm launches (A/B)."""
+def norm_folding_applies(hidden_size, intermediate_size, rms=False):
+    """The encoder folds its norms into the GEMMs around them
+      * at hidden size 1024 (ViT-L, InternViT-300M: rows of exactly four 256-column tiles, LayerNorm or RMSNorm), and
+      * round 5: for RMSNorm at any hidden size of up to 16 column tiles that is a multiple of 8 (InternViT-6B: 3200 = 12.5 tiles;
+        `rms=True`), where the C side keeps the launched norms for batches too small for the persistent GEMM schedule.
+    The C side also asks for >= 1024 tokens per call; VLLM_LN_FOLD=0 keeps the norm launches (A/B).  The prepared operands are one
+    more bf16 copy of the qkv and fc1 weights (InternViT-6B: 6.9 GB over 48 layers)."""
     import os
-    return os.environ.get("VLLM_LN_FOLD", "1") != "0" and hidden_size == 1024 and intermediate_size >= 1024
+    if os.environ.get("VLLM_LN_FOLD", "1") == "0" or intermediate_size < 1024:
+        return False
+    return hidden_size == 1024 or (rms and hidden_size % 8 == 0 and hidden_size <= 4096 and os.environ.get("VLLM_LN_FOLD_WIDE", "1") != "0")
 
 
 def kpad_for(patch):
