@@ -459,6 +459,24 @@ def test_unipose_module_vs_reference_module(tag):
     _bf16_vs_reference_arithmetic(ob, oc, g[f"{tag}.out_f64"], tag)
 
 
+def test_key_aware_signature_variant():
+    """unipose/ops/modules/ms_deform_attn_key_aware.py:83: ``forward(query, key, reference_points, ...)`` -- the reference's forward never
+    reads ``key``; the variant must give the plain module's result bit for bit on the reference-run fixture."""
+    g = load_golden("msda_layer.npz")
+    tag = "unipose_ref2"
+    M, L, P = int(g["n_heads"]), int(g["n_levels"]), int(g["n_points"])
+    C = g[f"{tag}.query"].shape[-1]
+    plain = _load_layer(g, tag, A.MSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=P))
+    aware = _load_layer(g, tag, A.MSDeformAttnKeyAware(d_model=C, n_levels=L, n_heads=M, n_points=P))
+    q, ref, src = _t(g[f"{tag}.query"]), _t(g[f"{tag}.ref"]), _t(g[f"{tag}.src"])
+    rest = (_t(g["shapes"]), _t(g["lsi"]), _t(g[f"{tag}.mask"]))
+    key = torch.randn(q.shape[0], 1, C, device=DEV)
+    with torch.no_grad():
+        a, b = plain(q, ref, src, *rest), aware(q, key, ref, src, *rest)
+        np.testing.assert_allclose(b.cpu().numpy(), g[f"{tag}.out_f32"], rtol=2e-5, atol=2e-5)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tag", ["mmcv_ref2", "mmcv_ref4"])
 def test_mmcv_module_vs_reference_module(tag):
     g = load_golden("msda_layer.npz")

@@ -2,7 +2,7 @@
 //   (a) one wave per SIMD, NCH independent chains of one opcode: cycles per instruction;
 //   (b) one wave per SIMD, 1 MFMA 32x32x16 followed by K independent VALU ops: cycles per group (what fits "under" an MFMA);
 //   (c) two waves per SIMD, one MFMA-only, one VALU-only: does the pair overlap.
-// Numbers quoted in DESIGN.md (attention "what bounds it").
+// Numbers quoted in NOTES/rounds_1_to_4.md section 3.3 (attention "what bounds it").
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));

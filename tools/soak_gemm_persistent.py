@@ -1,6 +1,6 @@
 """Repeat-run soak of the persistent GEMM schedule at the bench sizes: every launch of a shape must reproduce its first result bit for
 bit (outputs AND the folded norm's statistics), with the four shapes of a ViT-L layer interleaved the way the encoder issues them and
-an MSDA call on a side stream disturbing the timing.  The hazards found while bringing the kernel up (the four
+an MSDA call on a side stream disturbing the timing.  The hazards found while bringing the kernel up (NOTES/rounds_1_to_4.md section 3.2, the four
 properties) all showed as run-to-run differences in a handful of lanes: this is the test that would see one come back."""
 import math, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))

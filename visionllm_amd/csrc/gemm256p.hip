@@ -21,7 +21,7 @@
 // Scope: bias / GELU / quick-GELU / residual epilogues (qkv, fc1, proj, fc2 and the projector linears), N a multiple of 8, at
 // least as many tiles as CUs, no CLS-skipping loader; the launcher in gemm256.hip asks for this schedule before it considers a
 // stream-K tail.  Everything else stays on gemm256.hip.  VLLM_GEMM_PERSIST=0 / VLLM_GEMM_FORCE_TILEWISE switch it off.
-// Measured and the four properties of the part / toolchain that the guards in this file are for: DESIGN.md section 3.2.
+// Measured and the four properties of the part / toolchain that the guards in this file are for: DESIGN.md section 3.2 and NOTES/rounds_1_to_4.md section 3.2 ("Four properties ...").
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>

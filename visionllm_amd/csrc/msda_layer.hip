@@ -252,7 +252,7 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     uint16_t *opb = (uint16_t *)(ws + w.opout_bf16);
     prof_mark(PT_MSDA_LAYER, st);
     // value = value_proj(input_flatten), padded keys zeroed (ms_deform_attn.py:106-109) -- fp32 [B, S, M, D] where the LDS-tiled
-    // operator can run (its windows are fp32: a bf16 value would cost its gather conversions it has no issue slots for).
+    // operator can run (its windows are fp32: a bf16 value would cost its gather conversions it has no issue slots for, NOTES/rounds_1_to_4.md 3.6).
     // A query set that is NOT the value pyramid (decoder cross-attention: Lq != S) runs the gather kernel whatever the value's
     // dtype, and that one reads bf16 natively: the value is then stored in bf16 -- what the reference's own bf16 module computes
     // (...mask_dn.py:764-766 rounds it to bf16 before the upcast) at half the value GEMM's write and half the operator's read.
@@ -263,7 +263,10 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
         va.M = B * S; va.N = C; va.K = C; va.ldx = C; va.ldw = C; va.ldy = C; va.ldr = 0; va.P = 0; va.mt = va.nt = 0; va.xP = 0;
         va.variant = 0; va.variant256 = 0; va.direct_store = 0; va.row_mask = padding_mask;
     }
-    const bool v16 = Lq != S && msda_layer_value_bf16() && gemm_skinny_takes(EPI_BIAS, va);
+    // (the bf16-value operator needs 8 channels per lane: D / 8 a power of two, 8 <= D <= 512 -- vllm_msda_forward_bf16's own
+    //  precondition; a d_model-256 layer with 64 heads (D = 4) keeps the fp32 value path instead of failing there.  ADVICE r4)
+    const bool d_bf16_ok = D >= 8 && D <= 512 && D % 8 == 0 && ((D / 8) & (D / 8 - 1)) == 0;
+    const bool v16 = Lq != S && d_bf16_ok && msda_layer_value_bf16() && gemm_skinny_takes(EPI_BIAS, va);
     if (v16) TRY(gemm_bf16_launch(EPI_BIAS, va, st));
     else
     TRY(gemm(st, EPI_F32, input_flatten, C, d->value_proj_w, C, d->value_proj_b, (uint16_t *)value, C, B * S, C, C, nullptr,
@@ -294,7 +297,10 @@ extern "C" int vllm_msda_layer_forward(const VllmMsdaLayerDesc *d, const uint16_
     // the operator (:131-139), fp32 arithmetic; bf16 result straight from the LDS-tiled kernel where that one runs
     int where = 0;
     if (v16) TRY(vllm_msda_forward_bf16(value16, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opb, stream));   // (bf16 result: output_proj's operand)
-    else if (layer_unfused()) TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
+    else if (layer_unfused()) {
+        TRY(vllm_msda_forward_f32(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, stream));
+        prof_mark(PT_MSDA_LAYER, st);   // (the public entry point marks its own tag and closes it: the layer's tag goes on behind it)
+    }
     else TRY(msda_forward_f32_out16(value, shapes, lsi, off, lg, B, S, M, D, L, Lq, P, opout, opb, &where, st, d->geometry));
     // output_proj (:144).  The conversion pass runs unless the host KNOWS the operator wrote bf16 (pyramid hint); with an
     // unknown geometry it is enqueued and tests the device-side predicate itself.

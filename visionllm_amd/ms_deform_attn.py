@@ -463,6 +463,19 @@ class MSDeformAttn(nn.Module):
         return self.output_proj(output)
 
 
+class MSDeformAttnKeyAware(MSDeformAttn):
+    """The "key-aware" signature variant (unipose/ops/modules/ms_deform_attn_key_aware.py:33-132): same parameters, same arithmetic,
+    ``forward(query, key, reference_points, ...)`` with a ``key`` of shape (N, 1, C) that the reference's forward never reads (:83-132).
+    Not imported by modeling_unipose.py; provided so that ``from ...ms_deform_attn_key_aware import MSDeformAttn`` has a drop-in
+    (``visionllm_amd.compat`` users alias it)."""
+
+    def forward(self, query, key, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        del key   # (unused by the reference as well)
+        return super().forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                               input_padding_mask)
+
+
 class MultiScaleDeformableAttention(nn.Module):
     """mmcv module (mmcv/ops/multi_scale_deform_attn.py:162-367): (num_query, bs, C) unless batch_first, residual
     ``identity`` and dropout on the output."""
