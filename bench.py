@@ -467,6 +467,17 @@ def extra_rooflines(dev, entry):
                           HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
                           note="not part of the step (SURVEY 8 row a12 / 8f row 4); time includes the index bookkeeping in torch (mask, nonzero, has_image gather); "
                                "bytes = rows read + rows written")
+    # the native row mover alone (the same rows, indices already on the device): what the kernel does without torch's mask / nonzero
+    from visionllm_amd import _lib
+    idx = torch.nonzero((ids == 7).reshape(-1), as_tuple=False).reshape(-1).contiguous()
+    rows = feats.reshape(-1, Cc).contiguous()
+    L_ = _lib.lib()
+    f = lambda: _lib.check(L_.vllm_scatter_rows_bf16(_lib.ptr(rows), _lib.ptr(idx), _lib.ptr(emb), idx.numel(), Cc, B * Lt,  # noqa: E731
+                                                      _lib.current_stream(torch.device(dev))))
+    f(); torch.cuda.synchronize()
+    sec = event_time(f, 10)
+    out["splice_rows"] = entry("-", f"vllm_scatter_rows_bf16 alone ({idx.numel()} rows x {Cc} bf16, indices resident)", "hbm", ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9,
+                               algorithmic_bytes=ab, note="the kernel of `splice` without the index bookkeeping")
     return out
 
 

@@ -46,41 +46,112 @@ __device__ __forceinline__ float ps_eval(const float *__restrict__ plane, const 
     return v00 * k.w00 + v01 * k.w01 + v10 * k.w10 + v11 * k.w11;
 }
 
-// out[n, c, p]; one thread per output element, p fastest (coalesced stores, coordinates shared along c through L1/L2)
-__global__ __launch_bounds__(256) void point_sample_kernel(const float *__restrict__ in, const float *__restrict__ coords,
-                                                           float *__restrict__ out, long total, int C, int H, int W, int P)
+// Round 5: both kernels evaluate a point's corner geometry ONCE and walk a chunk of channels with it (rounds 1-4: one thread per
+// output element -- ~40 VALU of coordinate arithmetic per 4 loads and a store: 0.12 / 0.04 of the HBM roofline at the region
+// encoder's shapes, profiles/r05_bench_line.json).  The zero-weight guards (a NaN at a clamped address must not get through a zero
+// weight) are selects on the loaded values.
+struct PsGeo {
+    int o00, o01, o10, o11;     // clamped element offsets inside a plane
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ PsGeo ps_geo(float cx, float cy, int H, int W)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int p = (int)(i % P);
-    const long nc = i / P, n = nc / C;
-    const float2_t xy = *reinterpret_cast<const float2_t *>(coords + (n * P + p) * 2);
-    const PsCorner k = ps_corner(xy.x, xy.y, H, W);
-    out[i] = ps_eval(in + nc * (long)H * W, k, H, W);
+    const PsCorner k = ps_corner(cx, cy, H, W);
+    PsGeo g;
+    const int x0 = min(max(k.x0, 0), W - 1), x1 = min(max(k.x0 + 1, 0), W - 1);
+    const int y0 = min(max(k.y0, 0), H - 1), y1 = min(max(k.y0 + 1, 0), H - 1);
+    g.o00 = y0 * W + x0; g.o01 = y0 * W + x1; g.o10 = y1 * W + x0; g.o11 = y1 * W + x1;
+    g.w00 = k.any ? k.w00 : 0.f; g.w01 = k.any ? k.w01 : 0.f; g.w10 = k.any ? k.w10 : 0.f; g.w11 = k.any ? k.w11 : 0.f;
+    return g;
+}
+__device__ __forceinline__ float ps_eval_geo(const float *__restrict__ plane, const PsGeo &g)
+{
+    const float a = plane[g.o00], b = plane[g.o01], c = plane[g.o10], d = plane[g.o11];
+    const float v00 = g.w00 != 0.f ? a : 0.f, v01 = g.w01 != 0.f ? b : 0.f, v10 = g.w10 != 0.f ? c : 0.f, v11 = g.w11 != 0.f ? d : 0.f;
+    return v00 * g.w00 + v01 * g.w01 + v10 * g.w10 + v11 * g.w11;   // (the association of ps_eval: same bits as rounds 1-4)
 }
 
-// out[n, c] = masked mean over the points; one block per (n, c)
+constexpr int PS_CCH = 16;      // channel planes a block stages / a thread walks
+constexpr int PS_LDS_MAX = 48 * 1024;   // the planes of a block in LDS when they fit (24 x 24 x 16 x 4 B = 36 KiB at the region encoder's shape)
+
+// the block's PS_CCH planes [c][H * W] into LDS (coalesced 4-byte loads: a plane is only 16-byte aligned when H * W % 4 == 0)
+__device__ __forceinline__ void ps_stage(const float *__restrict__ planes, float *lds, int n_elems)
+{
+    for (int i = threadIdx.x; i < n_elems; i += 256) lds[i] = planes[i];
+    __syncthreads();
+}
+template <bool LDS>
+__device__ __forceinline__ float ps_eval_any(const float *plane_g, const float *plane_l, const PsGeo &g)
+{
+    return ps_eval_geo(LDS ? plane_l : plane_g, g);
+}
+
+// out[n, c, p]: grid (C / PS_CCH, N).  The block's channel planes are staged in LDS once (LDS = true; 2.3 KB each at 24 x 24) and every
+// thread walks points p = tid, tid + 256, ...: corner geometry once per point, then per channel four LDS reads, four multiply-adds and
+// one store (p fastest: 256 contiguous bytes per wave and channel).  LDS = false: the same walk straight from global memory (maps too
+// large to stage).
+template <bool LDS>
+__global__ __launch_bounds__(256) void point_sample_kernel(const float *__restrict__ in, const float *__restrict__ coords,
+                                                           float *__restrict__ out, int C, int H, int W, int P)
+{
+    extern __shared__ __attribute__((aligned(16))) float ps_lds[];
+    const int c0 = blockIdx.x * PS_CCH;
+    const long n = blockIdx.y;
+    const int HW = H * W, nc = min(PS_CCH, C - c0);
+    const float *planes = in + (n * C + c0) * (long)HW;
+    if (LDS) ps_stage(planes, ps_lds, nc * HW);
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const float2_t xy = *reinterpret_cast<const float2_t *>(coords + (n * P + p) * 2);
+        const PsGeo g = ps_geo(xy.x, xy.y, H, W);
+        float *o = out + (n * C + c0) * (long)P + p;
+#pragma unroll 4
+        for (int c = 0; c < nc; ++c) o[(long)c * P] = ps_eval_any<LDS>(planes + (long)c * HW, ps_lds + c * HW, g);
+    }
+}
+
+// out[n, c] = masked mean over the points: grid (C / PS_CCH, N); the same staging and walk with PS_CCH partial sums per thread; wave
+// reduction by xor shuffles, the four waves through LDS, in a fixed order
+template <bool LDS>
 __global__ __launch_bounds__(256) void point_sample_mean_kernel(const float *__restrict__ in, const float *__restrict__ coords,
                                                                 const uint8_t *__restrict__ valid, float *__restrict__ out, int C,
                                                                 int H, int W, int P)
 {
-    const long nc = blockIdx.x, n = nc / C;
-    const float *plane = in + nc * (long)H * W;
-    float s = 0.f, cnt = 0.f;
+    extern __shared__ __attribute__((aligned(16))) float ps_lds[];
+    const int c0 = blockIdx.x * PS_CCH;
+    const long n = blockIdx.y;
+    const int HW = H * W, nc = min(PS_CCH, C - c0);
+    const float *planes = in + (n * C + c0) * (long)HW;
+    if (LDS) ps_stage(planes, ps_lds, nc * HW);
+    float s[PS_CCH];
+#pragma unroll
+    for (int c = 0; c < PS_CCH; ++c) s[c] = 0.f;
+    float cnt = 0.f;
     for (int p = threadIdx.x; p < P; p += 256) {
         if (!valid[n * P + p]) continue;
         const float2_t xy = *reinterpret_cast<const float2_t *>(coords + (n * P + p) * 2);
-        s += ps_eval(plane, ps_corner(xy.x, xy.y, H, W), H, W);
+        const PsGeo g = ps_geo(xy.x, xy.y, H, W);
         cnt += 1.f;
-    }
-    __shared__ float rs[4], rc[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); cnt += __shfl_xor(cnt, o); }
-    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = cnt; }
+        for (int c = 0; c < PS_CCH; ++c)
+            if (c < nc) s[c] += ps_eval_any<LDS>(planes + (long)c * HW, ps_lds + c * HW, g);
+    }
+    __shared__ float rs[4][PS_CCH], rc[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+#pragma unroll
+        for (int c = 0; c < PS_CCH; ++c) s[c] += __shfl_xor(s[c], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        rc[threadIdx.x >> 6] = cnt;
+#pragma unroll
+        for (int c = 0; c < PS_CCH; ++c) rs[threadIdx.x >> 6][c] = s[c];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float ts = rs[0] + rs[1] + rs[2] + rs[3], tc = rc[0] + rc[1] + rc[2] + rc[3];
-        out[nc] = tc > 0.f ? ts / tc : 0.f;   // (x / 0).nan_to_num() of the reference
+    if ((int)threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        const float ts = (rs[0][c] + rs[1][c]) + (rs[2][c] + rs[3][c]), tc = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+        out[n * C + c0 + c] = tc > 0.f ? ts / tc : 0.f;   // (x / 0).nan_to_num() of the reference
     }
 }
 
@@ -97,8 +168,11 @@ extern "C" int vllm_point_sample_f32(const float *input, const float *coords, in
     if (total == 0) return VLLM_OK;
     VLLM_REQUIRE(input && coords && out, "point_sample: null pointer");
     VLLM_REQUIRE((reinterpret_cast<uintptr_t>(coords) & 7u) == 0, "point_sample: coords must be 8-byte aligned");
-    VLLM_LAUNCH(point_sample_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, input, coords, out,
-                total, C, H, W, P);
+    VLLM_REQUIRE(N <= 65535 && (long)H * W < (1L << 24), "point_sample: too many regions / too large a map for one launch");
+    const size_t lds = (size_t)PS_CCH * H * W * sizeof(float);
+    const dim3 grid((unsigned)ceil_div(C, PS_CCH), (unsigned)N);
+    if (lds <= (size_t)PS_LDS_MAX) VLLM_LAUNCH((point_sample_kernel<true>), grid, dim3(256), lds, (hipStream_t)stream, input, coords, out, C, H, W, P);
+    else VLLM_LAUNCH((point_sample_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, input, coords, out, C, H, W, P);
     VLLM_CHECK_LAUNCH("point_sample_kernel");
     return VLLM_OK;
 }
@@ -110,8 +184,11 @@ extern "C" int vllm_point_sample_mean_f32(const float *input, const float *coord
     if ((long)N * C == 0) return VLLM_OK;
     VLLM_REQUIRE(input && out && (P == 0 || (coords && valid)), "point_sample_mean: null pointer");
     VLLM_REQUIRE((reinterpret_cast<uintptr_t>(coords) & 7u) == 0, "point_sample_mean: coords must be 8-byte aligned");
-    VLLM_LAUNCH(point_sample_mean_kernel, dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, input, coords, valid,
-                out, C, H, W, P);
+    VLLM_REQUIRE(N <= 65535 && (long)H * W < (1L << 24), "point_sample_mean: too many regions / too large a map for one launch");
+    const size_t lds = (size_t)PS_CCH * H * W * sizeof(float);
+    const dim3 grid((unsigned)ceil_div(C, PS_CCH), (unsigned)N);
+    if (lds <= (size_t)PS_LDS_MAX) VLLM_LAUNCH((point_sample_mean_kernel<true>), grid, dim3(256), lds, (hipStream_t)stream, input, coords, valid, out, C, H, W, P);
+    else VLLM_LAUNCH((point_sample_mean_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, input, coords, valid, out, C, H, W, P);
     VLLM_CHECK_LAUNCH("point_sample_mean_kernel");
     return VLLM_OK;
 }
