@@ -1,14 +1,14 @@
-# One GPU-box pass that regenerates what profiles/r04_* quote at the end of round 4: full -m gpu suite, smoke, the default bench
+# One GPU-box pass that regenerates what profiles/r05_* quote at the end of round 5: full -m gpu suite, smoke, the default bench
 # line (ViT-L + the internvit6b key), rocprofv3 kernel stats of both workloads (csv), FETCH_SIZE / WRITE_SIZE PMC passes (separate
 # runs, kernel-trace only), the MSDA backward phase clocks.  The individual passes of the round, as they were run, are in
 # tools/gpu_passes/ (round 2's version of this script: git history).
-#   gpurun --timeout 2700 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r04z/* into profiles/ under their r04_ names
+#   gpurun --timeout 2700 -- 'bash tools/run_gpu_round.sh'      then copy gpurun_out/r05z/* into profiles/ under their r05_ names
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 export TMPDIR=/tmp
 make -C visionllm_amd/csrc -j16 2>&1 | tail -1   # (a stale .so once produced a wrong figure: rebuild whatever is out of date)
-O=gpurun_out/r04z
+O=gpurun_out/r05z
 mkdir -p $O
 rm -f gpurun_out/parity_contract.jsonl gpurun_out/ulp_table.jsonl
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt
@@ -26,8 +26,7 @@ find $O/prof_v $O/prof_i -type f -size +1M -delete
  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
 python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -30   # copy to profiles/pmc_traffic.json: bench.py reads `traffic` from there
 find $O/fetch $O/write -name '*.csv' -size +2M -delete
-python tools/msda_bwd_phases.py libmsdabwd_mfma_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_mfma_phases.txt
-python tools/msda_bwd_phases.py libmsdabwd_prof.so 2>&1 | grep -v amdgpu | tee $O/msda_bwd_lds_phases.txt
+timeout 300 python tools/prof_msda9.py 2>&1 | grep -v amdgpu | tee $O/msda9_phases.txt   # (the MSDA backward kernels are unchanged this round: profiles/r04_msda_bwd_mfma_phases.txt)
 # InternViT-6B traffic after the banded tile order (fc1 traffic <= 3x algorithmic)
 (cd /tmp; timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/fetch_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
