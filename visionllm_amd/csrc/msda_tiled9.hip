@@ -49,6 +49,9 @@
 #ifndef T9_DIET       // round 5, instruction diet of the preparing half (bit mask; profiles/r05_msda_diet.txt): 1 incremental window DMA,
 #define T9_DIET 63    // 2 leaner point arithmetic + packed box minima, 4 item decode by multiply-high, 8 six-product weights, 16 contiguous DMA runs per wave, 32 layout fast path + reciprocal magic, (64: slot words carried in a register -- spills 3 VGPRs, not in the default)
 #endif
+#ifndef T9_COLD_PIPE  // 1 (round 5): the global-memory levels' points two deep in flight; 0: the rolled loop of round 4
+#define T9_COLD_PIPE 1
+#endif
 #ifndef T9_GPRIO      // s_setprio of a wave while it gathers
 #define T9_GPRIO 2
 #endif
@@ -348,6 +351,57 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             const int Hc = EXACT ? H0 >> l : uni(s_dim[l]), Wc = EXACT ? W0 >> l : uni(s_dim[4 + l]);
             const float *vc = vbc + (size_t)__builtin_amdgcn_readlane(v0k, l) * MD;
             const int src = ((ln & ~3) | l) << 2;
+#if T9_COLD_PIPE
+            // Round 5: the four points of a cold level as a two-deep pipeline -- the 8 loads of point i + 1 are in flight under the
+            // multiply-adds of point i (two register sets of 32: the hot gather's sets are dead here).  The rolled loop of round 4
+            // paid one global-memory round trip per point, 4 per level and pass, and a cold item (6.8 % of the bench's items) took two to
+            // three half periods.  Same expressions in the same order per point: same bits.
+            struct ColdPt { float4_t a1, a2, a3, a4, d1, d2, d3, d4; float f1, f2, f3, f4; int m; };
+            auto cold_issue = [&](ColdPt &c, int oci, float w1i, float w2i, float w3i, float w4i) {
+                const int hwp = __builtin_amdgcn_ds_bpermute(src, oci);
+                const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w1i)));
+                const float e2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w2i)));
+                const float e3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w3i)));
+                const float e4 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w4i)));
+                const int bh = (hwp >> 16) - 1, bw = (hwp & 0xffff) - 1;
+                const bool u0 = bh >= 0, u1 = bh + 1 <= Hc - 1, l0 = bw >= 0, l1 = bw + 1 <= Wc - 1;
+                const int h0 = min(max(bh, 0), Hc - 1), h1 = min(max(bh + 1, 0), Hc - 1);
+                const int c0 = min(max(bw, 0), Wc - 1), c1 = min(max(bw + 1, 0), Wc - 1);
+                const float *p1 = vc + (size_t)((unsigned)(h0 * Wc + c0) * MD), *p2 = vc + (size_t)((unsigned)(h0 * Wc + c1) * MD);
+                const float *p3 = vc + (size_t)((unsigned)(h1 * Wc + c0) * MD), *p4 = vc + (size_t)((unsigned)(h1 * Wc + c1) * MD);
+                const int eA = cA / 4, eB = (cA ^ 64) / 4;
+                c.a1 = load4(p1 + eA); c.a2 = load4(p2 + eA); c.a3 = load4(p3 + eA); c.a4 = load4(p4 + eA);
+                c.d1 = load4(p1 + eB); c.d2 = load4(p2 + eB); c.d3 = load4(p3 + eB); c.d4 = load4(p4 + eB);
+                c.m = ((u0 && l0) ? 1 : 0) | ((u0 && l1) ? 2 : 0) | ((u1 && l0) ? 4 : 0) | ((u1 && l1) ? 8 : 0);
+                c.f1 = (u0 && l0) ? e1 : 0.f; c.f2 = (u0 && l1) ? e2 : 0.f; c.f3 = (u1 && l0) ? e3 : 0.f; c.f4 = (u1 && l1) ? e4 : 0.f;
+            };
+            auto cold_consume = [&](const ColdPt &c) {
+                const bool k1 = c.m & 1, k2 = c.m & 2, k3 = c.m & 4, k4 = c.m & 8;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    acc[ch] += c.f1 * (k1 ? c.a1[ch] : 0.f) + c.f2 * (k2 ? c.a2[ch] : 0.f) + c.f3 * (k3 ? c.a3[ch] : 0.f) + c.f4 * (k4 ? c.a4[ch] : 0.f);
+                    acc[4 + ch] += c.f1 * (k1 ? c.d1[ch] : 0.f) + c.f2 * (k2 ? c.d2[ch] : 0.f) + c.f3 * (k3 ? c.d3[ch] : 0.f) + c.f4 * (k4 ? c.d4[ch] : 0.f);
+                }
+            };
+            {
+                ColdPt ca, cb;
+                cold_issue(ca, oc[0], w1c[0], w2c[0], w3c[0], w4c[0]);
+                cold_issue(cb, oc[1], w1c[1], w2c[1], w3c[1], w4c[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_consume(ca);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_issue(ca, oc[2], w1c[2], w2c[2], w3c[2], w4c[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_consume(cb);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_issue(cb, oc[3], w1c[3], w2c[3], w3c[3], w4c[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_consume(ca);
+                __builtin_amdgcn_sched_barrier(0);
+                cold_consume(cb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             // (a ROLLED loop over the four points, the point's data picked by compares: this path runs for ~4 % of the items, and
             //  unrolled the compiler keeps 32 loads x 4 registers in flight -- a budget the pipelined gather above needs)
 #pragma unroll 1
@@ -381,6 +435,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             if (PROF) pacc[12] += 1;
         }
     };
