@@ -497,8 +497,8 @@ def cpu_baseline(ivit=False):
     """The setting we measured fastest (32 threads) is `value`.  The ALL-cores figure BASELINE.md section 2 asks for is reported beside
     it as `all_cores` -- from a BOUNDED probe: on the 256-thread hosts of this pool the same sample with torch.set_num_threads(256) is
     ~19x SLOWER (0.0091 against 0.174 images/sec, round 5: oversubscribed intra-op threads at these matrix sizes), i.e. ~2 minutes
-    per repetition, which the bench's few minutes cannot afford.  The probe times ONE tile of the ViT at both thread counts (no
-    warm-up, one repetition) and scales `value` by the ratio; headline workload only."""
+    per repetition, which the bench's few minutes cannot afford.  The probe times ONE tile through two layers of the ViT at both thread counts
+    (no warm-up, one repetition) and scales `value` by the ratio; headline workload only."""
     main_leg = _cpu_leg(ivit, min(32, os.cpu_count() or 1), reps=3)
     n_all = os.cpu_count() or 1
     if n_all <= main_leg["cores"]:
@@ -510,7 +510,7 @@ def cpu_baseline(ivit=False):
             from transformers import CLIPVisionConfig, CLIPVisionModel
             torch.manual_seed(0)
             with torch.no_grad():
-                model = CLIPVisionModel(CLIPVisionConfig(**VIT, attn_implementation="eager")).eval()
+                model = CLIPVisionModel(CLIPVisionConfig(**dict(VIT, num_hidden_layers=2), attn_implementation="eager")).eval()   # (2 of 24 layers: the 256-thread leg took 76 s for 24)
                 x = torch.randn(1, 3, 336, 336)
                 t = {}
                 for th in (main_leg["cores"], n_all):
@@ -521,7 +521,7 @@ def cpu_baseline(ivit=False):
             torch.set_num_threads(main_leg["cores"])
             ratio = t[main_leg["cores"]] / t[n_all]
             main_leg["all_cores"] = dict(value=main_leg["value"] * ratio, unit=main_leg["unit"], cores=n_all,
-                                         sample=(f"probe: ONE 336^2 tile through the 24-layer ViT, no warm-up, one repetition: {t[main_leg['cores']]:.2f}s at "
+                                         sample=(f"probe: ONE 336^2 tile through TWO layers of the ViT, no warm-up, one repetition: {t[main_leg['cores']]:.2f}s at "
                                                  f"{main_leg['cores']} threads, {t[n_all]:.2f}s at torch.set_num_threads({n_all}); value = the {main_leg['cores']}-thread "
                                                  f"figure x {ratio:.3f}"))
         except Exception as e:   # never fail the bench line for the second leg
