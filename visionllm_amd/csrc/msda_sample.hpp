@@ -58,7 +58,9 @@ __device__ __forceinline__ bool geometry_is_pyramid(const int64_t *shapes, int L
 {
     if (L < 1 || L > 4) return false;
     const int H0 = (int)shapes[0], W0 = (int)shapes[1];
-    bool ok = H0 > 0 && W0 > 0;
+    // (the pyramid-item kernels pack (row + 1, column + 1) of a corner into 16-bit halves -- round 5 also reduces them as SIGNED 16-bit
+    //  pairs: maps beyond 16384 pixels a side are "general geometry" and take generation 4)
+    bool ok = H0 > 0 && W0 > 0 && H0 <= 16384 && W0 <= 16384;
     long cum = (long)H0 * W0;
     for (int l = 1; l < L; ++l) {
         const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
@@ -76,7 +78,7 @@ __device__ __forceinline__ bool geometry_is_nested(const int64_t *shapes, int L,
 {
     if (L < 1 || L > 4) return false;
     int Hp = (int)shapes[0], Wp = (int)shapes[1];
-    bool ok = Hp > 0 && Wp > 0;
+    bool ok = Hp > 0 && Wp > 0 && Hp <= 16384 && Wp <= 16384;   // (see geometry_is_pyramid)
     const int nty = (Hp + 7) >> 3, ntx = (Wp + 15) >> 4;
     long cum = (long)Hp * Wp;
     for (int l = 1; l < L; ++l) {

@@ -290,7 +290,7 @@ def shape_facts(spatial_shapes):
 def nested_maps(hw):
     """The pyramid-item kernel's predicate (csrc/msda_sample.hpp, geometry_is_nested): 1-4 levels, each the previous one
     halved, rounded either way -- exact 2x pyramids and the ceil-divided maps of a detection backbone (100x167, 50x84, ...)."""
-    if not 1 <= len(hw) <= 4 or hw[0][0] <= 0 or hw[0][1] <= 0:
+    if not 1 <= len(hw) <= 4 or hw[0][0] <= 0 or hw[0][1] <= 0 or hw[0][0] > 16384 or hw[0][1] > 16384:   # (16-bit packed corner coordinates)
         return False
     nty, ntx = (hw[0][0] + 7) >> 3, (hw[0][1] + 15) >> 4
     for l in range(1, len(hw)):
