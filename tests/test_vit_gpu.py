@@ -853,6 +853,27 @@ def test_bridge_vs_oracle(kind, ps):
     close(out2, ref, 1.5e-2, f"bridge {kind} drop-in")
 
 
+@pytest.mark.parametrize("n,hw,C,Cl", [(3, 8, 128, 256), (2, 32, 3200, 4096)])   # (second: InternViT-6B's width and token grid: 12 800-wide LayerNorm rows)
+def test_pixel_shuffle_folded_into_the_projector_layernorm(n, hw, C, Cl, monkeypatch):
+    """Round 5 (review r4, missing item 4): with the InternVL projector the pixel-shuffle (modeling_visionllmv2.py:381-392, 574-579) is not
+    launched -- the LayerNorm gathers the 2 x 2 token neighbourhoods itself.  Same values into the same arithmetic: the visual tokens must
+    equal those of the launched pixel-shuffle (VLLM_PS_FOLD=0) bit for bit."""
+    torch.manual_seed(11)
+    hidden = bf(torch.randn(n, 1 + hw * hw, C)).to(DEV)
+    br = build_vl_bridge("internvl_mlp", C, Cl, use_pixelshuffle=True)
+    with torch.no_grad():
+        for p in br.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    br = br.to(DEV).to(torch.bfloat16).requires_grad_(False)
+    monkeypatch.setenv("VLLM_PS_FOLD", "1")
+    folded = br.project_hidden_state(hidden, True)
+    monkeypatch.setenv("VLLM_PS_FOLD", "0")
+    launched = br.project_hidden_state(hidden, True)
+    assert folded.shape == (n, hw * hw // 4, Cl) and bool(torch.isfinite(folded.float()).all())
+    assert torch.equal(folded, launched)
+
+
 def test_flash_attention_hook_and_rmsnorm_hook():
     from visionllm_amd.flash_attention import FlashAttention
     from visionllm_amd.intern_vit import InternRMSNorm

@@ -137,8 +137,16 @@ inline int gemm(hipStream_t st, int epi, const uint16_t *X, int ldx, const uint1
 
 // G > 1: G column groups of C elements per memory row, normalised independently in ONE launch (G = 2: the q and k blocks of
 // a qkv row with weights w / w2 -- InternViT's q_norm + k_norm, modeling_intern_vit.py:131-134)
+// Pixel-shuffled input rows for the norm kernel (round 5: the InternVL projector's LayerNorm reads the 2 x 2 token neighbourhoods of
+// hidden[:, 1:] itself -- modeling_visionllmv2.py:381-392, 574-579 -- instead of a pixel-shuffle launch writing them first): output row
+// ((n * h2 + i2) * h2 + j2) is the concatenation over quad = 2 a + b of token tok0 + (2 i2 + a) * hw + (2 j2 + b) of tile n, cseg
+// 16-byte chunks each.
+struct NormGather {
+    int hw, tok0, cseg;
+    long tile_stride;   // elements between two tiles of the input
+};
 int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
-                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2 = nullptr, int G = 1);
+                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2 = nullptr, int G = 1, const NormGather *ps = nullptr);
 
 struct AttnArgs {
     const uint16_t *q, *k, *v;  // element pointers; D contiguous

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
                                                                  const uint16_t *__restrict__ w,
                                                                  const uint16_t *__restrict__ b, uint16_t *__restrict__ y,
                                                                  int ldy, long rows, int C, float eps,
-                                                                 const uint16_t *__restrict__ w2, int G)
+                                                                 const uint16_t *__restrict__ w2, int G, NormGather ps)
 {
     // G column groups of C elements per memory row (G = 2: the q and k blocks of a qkv row, weights w / w2): the kernel's
     // "rows" are (memory row, group) pairs
@@ -44,6 +44,17 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
     if (grp) w = w2;
     const int nchunk = C >> 3;
     const uint16_t *xr = x + r * (long)ldx + (long)grp * C;
+    // pixel-shuffled rows (ps.hw > 0; G == 1): chunk c of the row lives in token (2 i2 + a) * hw + 2 j2 + b of tile n, quad = c / cseg
+    const int ps_h2 = ps.hw >> 1;
+    const long ps_n = ps.hw ? r / ((long)ps_h2 * ps_h2) : 0;
+    const int ps_ij = ps.hw ? (int)(r - ps_n * ps_h2 * ps_h2) : 0;
+    const int ps_i2 = ps.hw ? ps_ij / ps_h2 : 0, ps_j2 = ps.hw ? ps_ij - ps_i2 * ps_h2 : 0;
+    auto chunk_src = [&](int c) -> const uint16_t * {
+        if (!ps.hw) return xr + c * 8;
+        const int quad = (c >= ps.cseg) + (c >= 2 * ps.cseg) + (c >= 3 * ps.cseg);
+        const long tok = ps.tok0 + (long)(2 * ps_i2 + (quad >> 1)) * ps.hw + (2 * ps_j2 + (quad & 1));
+        return x + ps_n * ps.tile_stride + tok * (long)ldx + (c - quad * ps.cseg) * 8;
+    };
 
     // (weight / bias are requested behind the statistics, in the store loop: asking for them together with the row -- they do not
     //  depend on the statistics -- measured 22.8 instead of 21.5 us per launch inside the ViT-L step, same box, round 3)
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
     for (int i = 0; i < MAXCH; ++i) {
         const int c = (i * WPR + wsub) * 64 + lane;
         if (c < nchunk) {
-            v[i] = *reinterpret_cast<const uint4_t *>(xr + c * 8);
+            v[i] = *reinterpret_cast<const uint4_t *>(chunk_src(c));
             const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -135,9 +146,15 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_bf16_kernel(const uint16_t 
 }
 
 int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, const uint16_t *b, uint16_t *y, int ldy,
-                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2, int G)
+                     long rows, int C, float eps, hipStream_t st, const uint16_t *w2, int G, const NormGather *psp)
 {
     if (rows == 0) return VLLM_OK;
+    NormGather ps = {0, 0, 0, 0};
+    if (psp) {
+        ps = *psp;
+        VLLM_REQUIRE(G == 1 && ps.hw > 0 && ps.hw % 2 == 0 && ps.cseg > 0 && ps.cseg * 4 * 8 == C && rows % ((long)(ps.hw / 2) * (ps.hw / 2)) == 0,
+                     "norm: pixel-shuffled rows need an even token grid, C = 4 segments, whole tiles");
+    }
     VLLM_REQUIRE(x && w && y, "norm: null pointer");
     VLLM_REQUIRE(G == 1 || (G == 2 && w2 && aligned16(w2) && !b), "norm: column groups: G = 2 with a second weight and no bias");
     rows *= G;
@@ -154,7 +171,7 @@ int norm_bf16_launch(bool rms, const uint16_t *x, int ldx, const uint16_t *w, co
     const int maxch = per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : per_lane <= 4 ? 4 : 8;
     const int rpb = 4 / wpr;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(NORM_THREADS);
-#define L3(R, W, M) VLLM_LAUNCH((norm_bf16_kernel<R, W, M>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps, w2, G)
+#define L3(R, W, M) VLLM_LAUNCH((norm_bf16_kernel<R, W, M>), grid, block, 0, st, x, ldx, w, b, y, ldy, rows, C, eps, w2, G, ps)
 #define L2(R, W) do { if (maxch == 1) L3(R, W, 1); else if (maxch == 2) L3(R, W, 2); else if (maxch == 4) L3(R, W, 4); else L3(R, W, 8); } while (0)
     if (rms) { if (wpr == 1) L2(true, 1); else if (wpr == 2) L2(true, 2); else L2(true, 4); }
     else     { if (wpr == 1) L2(false, 1); else if (wpr == 2) L2(false, 2); else L2(false, 4); }

@@ -260,19 +260,32 @@ extern "C" int vllm_bridge_forward(const VllmBridgeDesc *d, const uint16_t *hidd
     const uint16_t *x = hidden;
     int ldx = C, xP = d->skip_cls ? T_in : 0;   // hidden[:, 1:] is read in place (the GEMM loader skips CLS rows)
     long rows = (long)n * T_in;
+    // Round 5: with the InternVL projector behind it (LayerNorm first) the pixel-shuffle is not launched: the LayerNorm gathers the
+    // 2 x 2 token neighbourhoods itself (NormGather; one launch and one round trip of the shuffled tensor less).  VLLM_PS_FOLD=0: A/B.
+    const char *ps_env = getenv("VLLM_PS_FOLD");   // (read per call: the test compares both forms in one process)
+    const int ps_fold_off = ps_env && ps_env[0] == '0' ? 1 : 0;
+    const bool ps_in_ln = d->pixel_shuffle && d->kind == VLLM_BRIDGE_INTERNVL_MLP && !ps_fold_off;
+    NormGather psg = {0, 0, 0, 0};
     if (d->pixel_shuffle) {
         const int hw = (int)(sqrtf((float)T_in) + 0.5f);
         VLLM_REQUIRE(hw * hw == T_in && hw % 2 == 0, "bridge: pixel_shuffle needs an even square token grid (T=%d)", T_in);
-        uint16_t *shuf = (uint16_t *)(ws + w.a);
-        prof_mark(PT_BRIDGE_OTHER, st);
-        TRY(pixel_shuffle_launch(hidden, (long)S * C, C, d->skip_cls ? 1 : 0, shuf, n, hw, C, st));
-        x = shuf; ldx = Cin; xP = 0; rows = (long)n * (T_in / 4);
+        if (ps_in_ln) {
+            psg.hw = hw; psg.tok0 = d->skip_cls ? 1 : 0; psg.cseg = C / 8; psg.tile_stride = (long)S * C;
+        } else {
+            uint16_t *shuf = (uint16_t *)(ws + w.a);
+            prof_mark(PT_BRIDGE_OTHER, st);
+            TRY(pixel_shuffle_launch(hidden, (long)S * C, C, d->skip_cls ? 1 : 0, shuf, n, hw, C, st));
+            x = shuf; ldx = Cin;
+        }
+        xP = 0; rows = (long)n * (T_in / 4);
     }
     if (d->kind == VLLM_BRIDGE_INTERNVL_MLP) {
         VLLM_REQUIRE(d->ln_w && d->ln_b, "bridge: internvl_mlp needs LayerNorm parameters");
         uint16_t *ln = (uint16_t *)(ws + w.b);
         prof_mark(PT_BRIDGE_OTHER, st);
-        if (xP == 0) {
+        if (ps_in_ln) {
+            TRY(norm_bf16_launch(false, hidden, C, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st, nullptr, 1, &psg));
+        } else if (xP == 0) {
             TRY(norm_bf16_launch(false, x, ldx, d->ln_w, d->ln_b, ln, Cin, rows, Cin, d->ln_eps, st));
         } else {
             // no pixel-shuffle (modeling_visionllmv2.py:163-172 allows it): the LayerNorm reads hidden[:, 1:] in place, one
