@@ -35,17 +35,6 @@ __device__ __forceinline__ PsCorner ps_corner(float cx, float cy, int H, int W)
     return k;
 }
 
-__device__ __forceinline__ float ps_eval(const float *__restrict__ plane, const PsCorner &k, int H, int W)
-{
-    if (!k.any) return 0.f;
-    const int x0 = min(max(k.x0, 0), W - 1), x1 = min(max(k.x0 + 1, 0), W - 1);
-    const int y0 = min(max(k.y0, 0), H - 1), y1 = min(max(k.y0 + 1, 0), H - 1);
-    // a zero weight must not let a NaN at a clamped address through
-    const float v00 = k.w00 != 0.f ? plane[y0 * W + x0] : 0.f, v01 = k.w01 != 0.f ? plane[y0 * W + x1] : 0.f;
-    const float v10 = k.w10 != 0.f ? plane[y1 * W + x0] : 0.f, v11 = k.w11 != 0.f ? plane[y1 * W + x1] : 0.f;
-    return v00 * k.w00 + v01 * k.w01 + v10 * k.w10 + v11 * k.w11;
-}
-
 // Round 5: both kernels evaluate a point's corner geometry ONCE and walk a chunk of channels with it (rounds 1-4: one thread per
 // output element -- ~40 VALU of coordinate arithmetic per 4 loads and a store: 0.12 / 0.04 of the HBM roofline at the region
 // encoder's shapes, profiles/r05_bench_line.json).  The zero-weight guards (a NaN at a clamped address must not get through a zero
@@ -68,7 +57,7 @@ __device__ __forceinline__ float ps_eval_geo(const float *__restrict__ plane, co
 {
     const float a = plane[g.o00], b = plane[g.o01], c = plane[g.o10], d = plane[g.o11];
     const float v00 = g.w00 != 0.f ? a : 0.f, v01 = g.w01 != 0.f ? b : 0.f, v10 = g.w10 != 0.f ? c : 0.f, v11 = g.w11 != 0.f ? d : 0.f;
-    return v00 * g.w00 + v01 * g.w01 + v10 * g.w10 + v11 * g.w11;   // (the association of ps_eval: same bits as rounds 1-4)
+    return v00 * g.w00 + v01 * g.w01 + v10 * g.w10 + v11 * g.w11;   // (the association of rounds 1-4: same bits)
 }
 
 constexpr int PS_CCH = 16;      // channel planes a block stages / a thread walks
