@@ -10,6 +10,9 @@ the ones the fixture was made with: the fixture's CRC is checked).  The toleranc
     "1e-3 bf16 tolerance" is met where it can be (MSDA fp32: 4e-6; single kernels: <= 1 bf16 ulp) and, for whole encoders, the bar is
     "not further from the fp32 truth than the reference's OWN bf16 arithmetic": relative rms <= 1.25 x the bf16 reference run's
     (per hidden state and for the visual tokens), worst element <= 2 x its worst element;
+  * element-wise comparisons use the fixture's strided subsample of 5 hidden states; WHOLE tensors are covered by digests of EVERY
+    hidden state and of the tokens (row and column projections on hash vectors: every element enters both), under the same kind of
+    bar: <= 1.25 x the digest error of the reference's bf16 run (`_check_digests`);
   * the measured numbers of every config are written to gpurun_out/parity_contract.jsonl (copied to profiles/ per round).
 """
 import ast
@@ -42,10 +45,41 @@ def _sub(t, ts, cs):
     return t[:, ::ts, ::cs].float().cpu()
 
 
+def _digests(t, tag):
+    """The whole-tensor digests of oracle/gen_golden_fullsize.py::digests, evaluated on the device in fp32: every row projected on a
+    hash vector over the channels, every channel on a hash vector over the rows -- every element enters both."""
+    t = t.float()
+    u = DW.hash_uniform(f"fullsize.{tag}.u", (t.shape[2],), 1.0, 0.0, device=t.device).float()
+    v = DW.hash_uniform(f"fullsize.{tag}.v", (t.shape[1],), 1.0, 0.0, device=t.device).float()
+    return torch.matmul(t, u).cpu(), torch.einsum("nsc,s->nc", t, v).cpu()
+
+
+def _check_digests(tag, g, key, kind, tensors):
+    """WHOLE tensors: the digests of EVERY hidden state / of the visual tokens against the fp32 reference run's,
+    with the reference's own bf16 run as the yardstick (same form as the element contract: <= 1.25 x its digest error, floor 3e-3)."""
+    worst = dict(config=tag, tensor=f"{kind}: whole-tensor digests", n_tensors=len(tensors), row_ratio=0.0, col_ratio=0.0)
+    for i, t in enumerate(tensors):
+        ours = _digests(t, key)
+        for j, name in enumerate(("rowproj", "colproj")):
+            ref = torch.from_numpy(g[f"{key}{i}.{name}"].astype(np.float32)) * float(g[f"{key}{i}.{name}.scale"])
+            assert ours[j].shape == ref.shape, (ours[j].shape, ref.shape)
+            rel = ((ours[j] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            lo = float(g[f"{key}_digest.lo_rel_rms_{name[:3]}"][i])
+            bound = max(1.25 * lo, 3e-3)
+            rk = f"{name[:3]}_ratio"
+            if rel / bound > worst[rk]:
+                worst.update({rk: rel / bound, f"{name[:3]}_worst": dict(index=i, rel_rms=rel, ref_bf16_rel_rms=lo)})
+            assert rel <= bound, dict(config=tag, tensor=f"{kind}[{i}].{name}", rel_rms=rel, ref_bf16_rel_rms=lo)
+    _record(worst)
+    print(json.dumps(worst))
+
+
 def _check(tag, g, hidden_states, tokens):
     ts, cs, tts, tcs = (int(v) for v in g["strides"])
     n_states = len(g["hs_stats.rms"])
     assert len(hidden_states) == n_states, (len(hidden_states), n_states)
+    _check_digests(tag, g, "hs", "hidden_state", list(hidden_states))
+    _check_digests(tag, g, "tok", "visual tokens", [tokens])
     rows = []
     for i in (int(v) for v in g["kept"]):
         ref = torch.from_numpy(g[f"hs{i}"].astype(np.float32))

@@ -55,11 +55,17 @@ __device__ unsigned long long g_bm_prof[16];   // phase clock of the diagnostics
 constexpr int BT_THREADS = 256;
 constexpr int BT_QPP = BT_THREADS / 8;   // 32 queries per pass (8 lanes x 4 channels = D 32)
 constexpr int BT_MAXL = 8;
-constexpr int BT_TH = 8, BT_TW = 16, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
+#ifndef BT_TILE_W
+#define BT_TILE_W 16
+#endif
+#ifndef BT_BLOCKS_PER_CU
+#define BT_BLOCKS_PER_CU 2
+#endif
+constexpr int BT_TH = 8, BT_TW = BT_TILE_W, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
 constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
 constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in floats (odd: the scatter's banks spread)
 constexpr int BT_MAXWIN = 1024;           // larger windows: direct atomics
-constexpr int BT_STAGE = 512;             // windows up to this many pixels are staged in LDS (in the S^T buffer, free during phase C) for the corner reads
+constexpr int BT_STAGE = 4 * BT_NQ;            // windows up to this many pixels are staged in LDS (in the S^T buffer, free during phase C) for the corner reads
 constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
 constexpr size_t BT_LDS = BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -78,7 +84,7 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float x)   // x + (
 __device__ __forceinline__ float sum8(float x) { return dpp_add<0x104>(dpp_add<0x4e>(dpp_add<0xb1>(x))); }
 
 template <bool DCN>
-__global__ __launch_bounds__(BT_THREADS, 2) void msda_bwd_mfma_kernel(
+__global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out, int B, int S, int M,
     int L, int Lq, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attw, const Dcnv3Geo dq,
@@ -497,7 +503,7 @@ int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BT_LDS);
     }
-    const int grid = (cus / 8) * 8 * 2;   // persistent: 2 blocks per CU
+    const int grid = (cus / 8) * 8 * BT_BLOCKS_PER_CU;   // persistent
     VLLM_LAUNCH(msda_bwd_mfma_kernel<false>, dim3(grid), dim3(BT_THREADS), BT_LDS, st, value, shapes, lsi, loc, attw, grad_out, B, S, M, L,
                 Lq, gv, gl, gw, Dcnv3Geo{}, 0.f);
     VLLM_CHECK_LAUNCH("msda_bwd_mfma_kernel");
@@ -521,7 +527,7 @@ int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)BT_LDS);
     }
-    const int grid = (cus / 8) * 8 * 2;
+    const int grid = (cus / 8) * 8 * BT_BLOCKS_PER_CU;
     const int L = (q.kh * q.kw + 3) / 4;
     VLLM_LAUNCH(msda_bwd_mfma_kernel<true>, dim3(grid), dim3(BT_THREADS), BT_LDS, st, input, nullptr, nullptr, offset, mask, grad_out, q.N,
                 q.H * q.W, q.G, L, q.Ho * q.Wo, grad_input, grad_offset, grad_mask, q, offset_scale);
