@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, pass 22: the backward tests on the rebuilt library (8 x 8 tiles, 3 blocks per CU) + DCNv3 backward with both tile configurations
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r05o
+timeout 1200 python -m pytest tests/test_msda_gpu.py tests/test_dcnv3_gpu.py tests/test_race_screen_gpu.py -x -q -k "backward or bwd or race or grad or autograd" 2>&1 | tail -8 > gpurun_out/r05o/bwd_tests.txt
+cat gpurun_out/r05o/bwd_tests.txt
+for lib in _build _build_w16; do
+  echo "== $lib"
+  DCN_BWD=1 VLLM_HIP_LIB=$GRAFT_REPO_ROOT/visionllm_amd/$lib/libvllm_hip.so timeout 300 python tools/bench_dcnv3.py 2>&1 | grep backward
+done > gpurun_out/r05o/dcn_bwd_tiles.txt 2>&1
+cat gpurun_out/r05o/dcn_bwd_tiles.txt

@@ -257,7 +257,8 @@ extern "C" int vllm_dcnv3_backward_f32(const float *input, const float *offset, 
     VLLM_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "dcnv3_backward_f32: null pointer");
     // group channels 32 (InternImage-H style stages): the windowed kernel -- grad_input as S^T x grad_out on the fp32 MFMA, one global
     // atomic per (window pixel, channel) instead of one per (point, corner, channel) (msda_bwd_mfma.hip, template flag DCN)
-    if (dcnv3_bwd_tiled() && dcnv3_bwd_mfma_takes(q) && aligned16(input) && aligned16(grad_output) && (reinterpret_cast<uintptr_t>(offset) & 7u) == 0)
+    if (dcnv3_bwd_tiled() && dcnv3_bwd_mfma_takes(q) && aligned16(input) && aligned16(grad_output) && (reinterpret_cast<uintptr_t>(offset) & 7u) == 0 &&
+        (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0)
         return dcnv3_bwd_mfma_launch(input, offset, mask, grad_output, q, offset_scale, grad_input, grad_offset, grad_mask, (hipStream_t)stream);
     return dcnv3_bwd_launch<float>(input, offset, mask, grad_output, q, offset_scale, grad_input, grad_offset, grad_mask, (hipStream_t)stream);
 }

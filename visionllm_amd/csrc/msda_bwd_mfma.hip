@@ -34,13 +34,21 @@
 #include "dcnv3_geo.hpp"
 
 // Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (large-window) atomics, 4: no S scatter,
-// 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no MFMA, 64: no grad_value rounds at all.
+// 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no MFMA, 64: no grad_value rounds at all,
+// 128: the flush as plain stores.
 #ifndef BT_ABL
 #define BT_ABL 0
 #endif
 
+#ifdef BT_SCHED_FENCE    // keeps the scheduler from hoisting one point's LDS reads over the previous point (register pressure)
+#define BT_SB __builtin_amdgcn_sched_barrier(0);
+#else
+#define BT_SB
+#endif
 #ifdef BT_PROF
 #define BT_TICK(slot) { const unsigned now__ = (unsigned)__builtin_amdgcn_s_memtime(); pacc[slot] += now__ - tprev; tprev = now__; }
+#elif defined(BT_MARKS)
+#define BT_TICK(slot) asm volatile("; BT_MARK " #slot);
 #else
 #define BT_TICK(slot)
 #endif
@@ -56,19 +64,32 @@ constexpr int BT_THREADS = 256;
 constexpr int BT_QPP = BT_THREADS / 8;   // 32 queries per pass (8 lanes x 4 channels = D 32)
 constexpr int BT_MAXL = 8;
 #ifndef BT_TILE_W
-#define BT_TILE_W 16
+#define BT_TILE_W 8
 #endif
 #ifndef BT_BLOCKS_PER_CU
-#define BT_BLOCKS_PER_CU 2
+#define BT_BLOCKS_PER_CU 3
+#endif
+#ifndef BT_DIRECT        // 1: a lane loads its own point's location / weight from global memory (no hand-over through LDS, two barriers
+#define BT_DIRECT 1      //    per level fewer); 0: rounds 3-4 (two loader threads per query, s_loc / s_aw)
+#endif
+#ifndef BT_CULL          // 1: the grad_value product skips the k-steps (groups of 8 query slots) that have no corner in the wave's 32 pixels
+#define BT_CULL 1
+#endif
+#ifndef BT_GOR_LEVEL     // 1: the grad_out operand of the grad_value product is re-read (L2) per level behind phase C instead of living
+#define BT_GOR_LEVEL 0   //    in BT_NQ / 2 registers across the whole item
 #endif
 constexpr int BT_TH = 8, BT_TW = BT_TILE_W, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
 constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
 constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in floats (odd: the scatter's banks spread)
-constexpr int BT_MAXWIN = 1024;           // larger windows: direct atomics
-constexpr int BT_STAGE = 4 * BT_NQ;            // windows up to this many pixels are staged in LDS (in the S^T buffer, free during phase C) for the corner reads
+#ifndef BT_MAXWIN_PX
+#define BT_MAXWIN_PX 8192
+#endif
+constexpr int BT_MAXWIN = BT_MAXWIN_PX;   // larger windows (a tile of coarse-level queries on a fine map: few points on many pixels): one atomic per (point, corner, channel), two whole pixel rows per wave instruction
+constexpr int BT_STAGE = (BT_NQ * BT_RP * 4) / 128;   // pixels of the S^T buffer (free during phase C): a window is staged there for the corner reads when it fits with a guard of ww + 1 pixels on either side
 constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
-constexpr size_t BT_LDS = BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
+constexpr size_t BT_LDS = BT_DIRECT ? BT_LDS_WIN : BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef int int2_t __attribute__((ext_vector_type(2)));
 
 template <int K> __device__ __forceinline__ float qbc(float x)   // value of lane K of this lane's quad
 {
@@ -79,9 +100,21 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float x)   // x + (
 {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
+template <int CTRL> __device__ __forceinline__ float dpp_get(float x)   // x of the lane CTRL selects
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 // sum over the 8 lanes {8 n .. 8 n + 7}; valid in lane 8 n (quad butterfly: quad_perm [1,0,3,2], [2,3,0,1]; then row_shl:4 brings
 // the upper quad's sum down: lane i reads lane i + 4)
 __device__ __forceinline__ float sum8(float x) { return dpp_add<0x104>(dpp_add<0x4e>(dpp_add<0xb1>(x))); }
+
+// block-uniform values that come out of LDS: tell the compiler (scalar registers, scalar arithmetic, scalar address offsets)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long uni(long x)
+{
+    return (long)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)x >> 32)) << 32) |
+                  (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)x));
+}
 
 template <bool DCN>
 __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_kernel(
@@ -98,13 +131,17 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
     float *s_aw = reinterpret_cast<float *>(smem + BT_LDS_WIN + BT_LDS_LOC);       // [128 queries][4 points]
     __shared__ int s_H[BT_MAXL], s_W[BT_MAXL], s_q0[BT_MAXL], s_tc[BT_MAXL + 1];
     __shared__ long s_v0[BT_MAXL];
-    __shared__ int s_red[4][4];
+    __shared__ int2_t s_rows[2][BT_NQ / 8];
+    __shared__ int s_red[2][4][4];   // (two parities: a wave may start the next level pass while another still reads this one's)
     __shared__ int s_geo_ok;
+    __shared__ __attribute__((aligned(16))) unsigned s_poff[BT_R];   // byte offset of the round's window pixels inside the (batch, level, head) slice
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, hi = lane >> 5;
     const int sub = tid & 7;      // 4-channel chunk of this lane
-    const int kpt = tid & 3;      // the sampling point this lane evaluates for its quad
+    // the sampling point this lane evaluates: lane K of the LOWER quad of a query's 8 lanes owns point K, lane K of the UPPER quad point
+    // (K + 2) & 3 -- one DPP broadcast of quad lane K gives the lower quad point K and the upper quad point K + 2 (phase C)
+    const int kpt = (tid + ((tid >> 1) & 2)) & 3;
     const int slot0 = tid >> 3;   // query slot inside a pass
     const long MD = (long)M * D;
 
@@ -131,14 +168,15 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
     unsigned pacc[16] = {};
     unsigned tprev = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-    const bool geo = s_geo_ok != 0;
-    const int n_tiles = geo ? s_tc[L] : (Lq + BT_TW - 1) / BT_TW;
+    const bool geo = uni(s_geo_ok) != 0;
+    const int n_tiles = uni(geo ? s_tc[L] : (Lq + BT_TW - 1) / BT_TW);
     const long n_items = (long)B * M * n_tiles;
     const int xcd = blockIdx.x & 7;
     const long ipx = (n_items + 7) >> 3;
     const int blocks_per_xcd = gridDim.x >> 3;
 
     for (int i = tid; i < (BT_NQ * BT_RP + 3) / 4; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    int red_par = 0;
     for (long j = blockIdx.x >> 3; j < ipx; j += blocks_per_xcd) {
         const long item = (long)xcd * ipx + j;
         if (item >= n_items) break;
@@ -153,9 +191,9 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             ty = t / txn; tx = t - ty * txn;
         } else if (geo) {
             int lq = 0;
-            while (lq + 1 < L && s_tc[lq + 1] <= t) ++lq;
-            qH = s_H[lq]; qW = s_W[lq]; q0 = s_q0[lq];
-            const int txn = (qW + BT_TW - 1) / BT_TW, tl = t - s_tc[lq];
+            while (lq + 1 < L && uni(s_tc[lq + 1]) <= t) ++lq;
+            qH = uni(s_H[lq]); qW = uni(s_W[lq]); q0 = uni(s_q0[lq]);
+            const int txn = (qW + BT_TW - 1) / BT_TW, tl = t - uni(s_tc[lq]);
             ty = tl / txn; tx = tl - ty * txn;
         } else {
             qH = 1; qW = Lq; q0 = 0; ty = 0; tx = t;
@@ -179,13 +217,56 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
         // B operand of the grad_value product: grad_out[query 2 s + hi][channel l31], s = 0 .. 63 (zero for slots outside the map);
         // it stays in registers for all levels and rounds of the item
         float gor[BT_NQ / 2];
+        // slot 2 s + hi = (row (2 s) / BT_TW, column (2 s) % BT_TW + hi) of the tile: ONE block-uniform base address (a scalar register
+        // pair) + a 32-bit byte offset per load = the lane's constant part + a scalar
+        const char *gor_base = reinterpret_cast<const char *>(grad_out + ((b * Lq + q0 + (long)(ty * BT_TH) * qW + tx * BT_TW) * M + m) * D);
+        const unsigned gor_lane = (unsigned)(hi * (int)MD + l31) * 4u;
+        auto load_gor = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < BT_NQ / 2; ++s2) {
-            bool ok;
-            const long pr = pair_of(2 * s2 + hi, ok);
-            const float v = grad_out[pr * D + l31];
-            gor[s2] = ok ? v : 0.f;
-        }
+            for (int s2 = 0; s2 < BT_NQ / 2; ++s2) {
+                const int dy = (2 * s2) / BT_TW, dx = (2 * s2) % BT_TW;
+                const bool ok = ty * BT_TH + dy < qH && tx * BT_TW + dx + hi < qW;
+                const unsigned off = (unsigned)((dy * qW + dx) * (int)MD) * 4u + gor_lane;
+                const float v = *reinterpret_cast<const float *>(gor_base + (ok ? off : 0u));
+                gor[s2] = ok ? v : 0.f;
+            }
+        };
+        if (!BT_GOR_LEVEL) load_gor();
+#if BT_DIRECT
+        // this lane's point (kpt) of its query of pass p at level l: 8 + 4 bytes straight from global memory (the 4 points of a query
+        // are one 32-byte / 16-byte piece; lanes sub and sub + 4 read the same words), requested one level ahead.
+        // DCNv3: offset -> location in input pixels, the reference's arithmetic (dcnv3_im2col_cuda.cuh:300-334: p0 = centre of the
+        // kernel footprint, point (i, j) of the kw x kh grid in w-major order); a slot beyond kh * kw gets (-2, -2): rejected.
+        float2_t nloc[BT_NPASS];
+        float naw[BT_NPASS];
+        auto load_points = [&](int l) {
+#pragma unroll
+            for (int p = 0; p < BT_NPASS; ++p) {
+                if (!DCN) {
+                    nloc[p] = *reinterpret_cast<const float2_t *>(loc + ((qidx[p] * L + l) * PT + kpt) * 2);
+                    naw[p] = attw[(qidx[p] * L + l) * PT + kpt];
+                } else {
+                    const int slot = p * BT_QPP + slot0, y = ty * BT_TH + slot / BT_TW, x = tx * BT_TW + slot % BT_TW;
+                    const int p0_w = ((dq.dw * (dq.kw - 1)) >> 1) - dq.pw + x * dq.sw, p0_h = ((dq.dh * (dq.kh - 1)) >> 1) - dq.ph + y * dq.sh;
+                    // (every product rounded on its own -- mul_rn, msda_sample.hpp: the backend would fuse mul + add into one fma, and one ulp
+                    //  of a location of ~100 pixels is 8e-6 of a pixel: visible in the bilinear weights)
+                    const float dp0w = (float)p0_w - mul_rn((float)((dq.dw * (dq.kw - 1)) >> 1), dscale);
+                    const float dp0h = (float)p0_h - mul_rn((float)((dq.dh * (dq.kh - 1)) >> 1), dscale);
+                    const int j = l * PT + kpt;
+                    nloc[p] = (float2_t){-2.f, -2.f};
+                    naw[p] = 0.f;
+                    if (j < DP) {
+                        const float2_t o2 = *reinterpret_cast<const float2_t *>(loc + (qidx[p] * DP + j) * 2);
+                        const int i = j / dq.kh, jj = j - i * dq.kh;
+                        nloc[p].x = dp0w + mul_rn((float)(i * dq.dw) + o2.x, dscale);
+                        nloc[p].y = dp0h + mul_rn((float)(jj * dq.dh) + o2.y, dscale);
+                        naw[p] = attw[qidx[p] * DP + j];
+                    }
+                }
+            }
+        };
+        load_points(0);
+#else
         bool lq_ok, aq_ok;
         const long lq_pair = pair_of(tid >> 1, lq_ok);
         const long aq_pair = pair_of(tid & (BT_NQ - 1), aq_ok);
@@ -230,12 +311,15 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
         float4_t naw = {0.f, 0.f, 0.f, 0.f};
         if (tid < BT_NQ) naw = load_aw(0);
 
+#endif
+
         BT_TICK(0)   // item set-up: decode, grad_output / first level's locations requested
         for (int l = 0; l < L; ++l) {
-            const int H = s_H[l], W = s_W[l];
-            const long lbase = (b * (long)S + s_v0[l]) * MD + (long)m * D;   // (batch, level, head) origin, channel 0
+            const int H = uni(s_H[l]), W = uni(s_W[l]);
+            const long lbase = (b * (long)S + uni(s_v0[l])) * MD + (long)m * D;   // (batch, level, head) origin, channel 0
             const float *vl = value + lbase + sub * 4;
 
+#if !BT_DIRECT
             __syncthreads();   // previous level / item: every read of s_loc, s_aw, gwin, s_red is finished
             if (lthr) reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
             if (tid < BT_NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
@@ -244,17 +328,24 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 if (tid < BT_NQ) naw = load_aw(l + 1);
             }
             __syncthreads();
+#endif
             BT_TICK(1)   // two barriers around the hand-over of this level's locations / weights
 
             // ---- A: this lane's point (kpt) of each of its 4 queries; exact bounding window of all corners ----
             float him[BT_NPASS], wim[BT_NPASS], awp[BT_NPASS];
             int hlo[BT_NPASS], wlo[BT_NPASS], okp[BT_NPASS];
-            int ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1;
+            int xmin = 0x7fffffff, xmax = -1;
+            int rlo[BT_NPASS], rhi[BT_NPASS];   // rows of the corners of this lane's point per pass: (wave, pass) = one group of 8 query slots
 #pragma unroll
             for (int p = 0; p < BT_NPASS; ++p) {
                 const int slot = p * BT_QPP + slot0;
+#if BT_DIRECT
+                const float2_t xy = nloc[p];
+                awp[p] = naw[p];
+#else
                 const float2_t xy = s_loc[slot * PT + kpt];
                 awp[p] = s_aw[slot * PT + kpt];
+#endif
                 SamplePoint<float> sp;
                 if (DCN) {   // xy is the location in input pixels already; acceptance and floor as dcnv3_im2col_cuda.cuh:335-336, 92-93
                     sp.h_im = xy.y; sp.w_im = xy.x;
@@ -264,25 +355,42 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 } else sp = sample_point<float>(xy.x, xy.y, H, W);
                 him[p] = sp.h_im; wim[p] = sp.w_im; hlo[p] = sp.h_low; wlo[p] = sp.w_low;
                 okp[p] = (sp.ok && qok[p] && H > 0 && W > 0) ? 1 : 0;   // (empty level: no corner inside, nothing to do)
+                rlo[p] = 0x7fffffff; rhi[p] = -1;
                 if (okp[p]) {
                     const int h0 = min(max(sp.h_low, 0), H - 1), h1 = min(max(sp.h_low + 1, 0), H - 1);
                     const int x0 = min(max(sp.w_low, 0), W - 1), x1 = min(max(sp.w_low + 1, 0), W - 1);
-                    ymin = min(ymin, h0); ymax = max(ymax, h1); xmin = min(xmin, x0); xmax = max(xmax, x1);
+                    rlo[p] = h0; rhi[p] = h1; xmin = min(xmin, x0); xmax = max(xmax, x1);
                 }
             }
-            int r0 = ymin, r1 = -ymax, r2 = xmin, r3 = -xmax;
+#if BT_DIRECT
+            if (l + 1 < L) load_points(l + 1);
+#endif
+            int r2 = xmin, r3 = -xmax;
+#pragma unroll
+            for (int p = 0; p < BT_NPASS; ++p) rhi[p] = -rhi[p];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                r0 = min(r0, __shfl_xor(r0, o)); r1 = min(r1, __shfl_xor(r1, o));
                 r2 = min(r2, __shfl_xor(r2, o)); r3 = min(r3, __shfl_xor(r3, o));
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) { rlo[p] = min(rlo[p], __shfl_xor(rlo[p], o)); rhi[p] = min(rhi[p], __shfl_xor(rhi[p], o)); }
             }
-            if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
+            int r0 = rlo[0], r1 = rhi[0];
+#pragma unroll
+            for (int p = 1; p < BT_NPASS; ++p) { r0 = min(r0, rlo[p]); r1 = min(r1, rhi[p]); }
+            int2_t *rows = s_rows[red_par];   // [group of 8 slots] = (first row, -last row) of its corners: which k-steps of the product touch which pixels
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) rows[p * 4 + wave] = (int2_t){rlo[p], rhi[p]};
+            }
+            int (*red)[4] = s_red[red_par];
+            red_par ^= 1;
+            if (lane == 0) { red[wave][0] = r0; red[wave][1] = r1; red[wave][2] = r2; red[wave][3] = r3; }
             BT_TICK(2)   // A: points + window reduction inside the wave
-            __syncthreads();
-            const int y0 = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
-            const int y1 = -min(min(s_red[0][1], s_red[1][1]), min(s_red[2][1], s_red[3][1]));
-            const int x0w = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
-            const int x1w = -min(min(s_red[0][3], s_red[1][3]), min(s_red[2][3], s_red[3][3]));
+            __syncthreads();   // (also: the previous level pass's un-scatter stores are behind every wave before this one stages its window)
+            const int y0 = uni(min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])));
+            const int y1 = -uni(min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
+            const int x0w = uni(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])));
+            const int x1w = -uni(min(min(red[0][3], red[1][3]), min(red[2][3], red[3][3])));
             if (y1 < 0) {   // no accepted point at this level (block-uniform): MSDA: all three gradients stay zero (the caller's fill)
                 if (DCN && sub == 0) {   // DCNv3 writes every slot of grad_offset / grad_mask
 #pragma unroll
@@ -298,140 +406,201 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
-            const bool use_stage = npix <= BT_STAGE;  // block-uniform
+            // staged window: pixel (wy, wx) at byte ((ww + 1) + wy ww + wx) 128.  The guard of ww + 1 pixels in front and behind keeps the
+            // four corner addresses of every accepted point inside the buffer (row -1 / H, column -1 / W: their sums are discarded).
+            // A window that does not fit is staged in BANDS of rows (a band of hb rows of first corners needs hb + 1 rows): phase C runs
+            // once per band for the points whose first corner row lies in it.  Wider than a band of two rows: the cold path.
+            const int guard = (ww + 1) * 128;
+            const int cap_rows = (BT_STAGE - 2 * (ww + 1) - 8) / ww;   // rows that fit
+            const bool use_stage = cap_rows >= wh || cap_rows >= 2;  // block-uniform
+            const int hb = cap_rows >= wh ? wh : cap_rows - 1;       // rows of first corners per band
             BT_TICK(3)   // window barrier
-            // ---- B: the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave instruction, LDS-DMA.  The
-            //      window only holds pixels of the map (its box comes from clamped corners), so there is nothing to zero-fill.
-            if (use_stage && !(BT_ABL & 8)) {
-                const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
-                for (int p0 = wave * 8; p0 < npix; p0 += 32) {
-                    const int pix = min(p0 + (lane >> 3), npix - 1);
-                    const int wy = (int)(((unsigned)pix * ww_m) >> 20), wx = pix - wy * ww;
-                    const float *src = value + lbase + ((long)(y0 + wy) * W + (x0w + wx)) * MD + (lane & 7) * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(smem + p0 * 128), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
             BT_TICK(8)   // B: window staging
 
-            // ---- C: per (query, point): corner reads, the two per-point gradients, grad_value into the window ----
-            float *gvl = grad_value + lbase + sub * 4;
-#define BT_POINT(K)                                                                                                    \
-    {                                                                                                                  \
-        const int hl = qbc<K>(hlo[p]), wl = qbc<K>(wlo[p]);                                                            \
-        const bool pok = qbc<K>(okp[p]) != 0;                                                                          \
-        const float bh = qbc<K>(him[p]), bw = qbc<K>(wim[p]), aw = qbc<K>(awp[p]);                                     \
-        const float lh = bh - (float)hl, lw = bw - (float)wl;                                                          \
-        const float hh = 1.f - lh, hw = 1.f - lw;                                                                      \
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;                                            \
-        const bool k1 = pok && hl >= 0 && wl >= 0, k2 = pok && hl >= 0 && wl + 1 <= W - 1;                             \
-        const bool k3 = pok && hl + 1 <= H - 1 && wl >= 0, k4 = pok && hl + 1 <= H - 1 && wl + 1 <= W - 1;             \
-        const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);                                        \
-        const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);                                        \
-        const long g1 = ((long)h0 * W + x0) * MD, g2 = ((long)h0 * W + x1) * MD;                                       \
-        const long g3 = ((long)h1 * W + x0) * MD, g4 = ((long)h1 * W + x1) * MD;                                       \
-        const float4_t zz = {0.f, 0.f, 0.f, 0.f};                                                                     \
-        const float4_t v1 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g1);                          \
-        const float4_t v2 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g2);                          \
-        const float4_t v3 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g3);                          \
-        const float4_t v4 = (BT_ABL & 8) ? zz : *reinterpret_cast<const float4_t *>(vl + g4);                          \
-        float *d1 = gvl + g1, *d2 = gvl + g2, *d3 = gvl + g3, *d4 = gvl + g4;                                          \
-        float g_aw = 0.f, g_x = 0.f, g_y = 0.f;                                                                        \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                \
-            const float top = go[p][c], tgv = top * aw;                                                                \
-            const float a1 = k1 ? v1[c] : 0.f, a2 = k2 ? v2[c] : 0.f, a3 = k3 ? v3[c] : 0.f, a4 = k4 ? v4[c] : 0.f;    \
-            const float ghw = -hw * a1 - lw * a2 + hw * a3 + lw * a4;                                                  \
-            const float gww = -hh * a1 + hh * a2 - lh * a3 + lh * a4;                                                  \
-            if (!use_win && !(BT_ABL & 2)) {                                                                         \
-                if (k1) unsafeAtomicAdd(d1 + c, w1 * tgv);                                                             \
-                if (k2) unsafeAtomicAdd(d2 + c, w2 * tgv);                                                             \
-                if (k3) unsafeAtomicAdd(d3 + c, w3 * tgv);                                                             \
-                if (k4) unsafeAtomicAdd(d4 + c, w4 * tgv);                                                             \
-            }                                                                                                          \
-            const float val = w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4;                                                   \
-            g_aw += top * val;                                                                                         \
-            g_x += (DCN ? dscale : (float)W) * gww * tgv;                                                              \
-            g_y += (DCN ? dscale : (float)H) * ghw * tgv;                                                              \
-        }                                                                                                              \
-        _Pragma("unroll") for (int o = 4; o > 0; o >>= 1) {                                                            \
-            g_aw += __shfl_xor(g_aw, o); g_x += __shfl_xor(g_x, o); g_y += __shfl_xor(g_y, o);                         \
-        }                                                                                                              \
-        if (sub == 0 && (DCN ? (qok[p] && l * PT + K < DP) : pok) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
-            const long pi = DCN ? qidx[p] * DP + l * PT + K : (qidx[p] * L + l) * PT + K;                              \
-            grad_attw[pi] = pok ? g_aw : 0.f;                                                                          \
-            grad_loc[2 * pi] = pok ? g_x : 0.f;                                                                        \
-            grad_loc[2 * pi + 1] = pok ? g_y : 0.f;                                                                    \
-        }                                                                                                              \
-    }
+            // ---- C: per (query, point): the four corner reads and the two per-point gradients ----
             // Staged window (the common case): the per-point gradients only need the four dot products  d_i = <grad_out, corner i>
             // over the 32 channels:  grad_attw = sum_i w_i d_i,  grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),
-            // grad_y = H aw (hw (d3 - d1) + lw (d4 - d2))  -- 16 multiply-adds per lane and point instead of ~100, the sums over the
-            // 8 lanes of a query by DPP adds (quad butterfly, then the upper quad onto the lower one: lane 0 of the 8 owns the result).
-#define BT_LEAN_POINT(K)                                                                                               \
+            // grad_y = H aw (hw (d3 - d1) + lw (d4 - d2)).  The 8 lanes of a query (4 channels each) walk its four points in four steps --
+            // the lower quad in the order 0 1 2 3, the upper quad 2 3 0 1 -- and of a point they only need the byte address of its first
+            // corner (one DPP broadcast from the lane that owns the point): 4 LDS reads and 12 packed multiply-adds per step.  The sums
+            // over the 8 lanes are a reduce-scatter: one exchange between the quads (row_half_mirror: step t of one quad meets step
+            // t + 2 of the other -- the SAME point -- so the lower quad ends up with points 0, 1 and the upper quad with 2, 3: no
+            // selects), then a butterfly inside the quad: 24 DPP adds per query and level instead of 48.  Lanes 0, 1 of either quad
+            // own exactly the points they hold the sums of, and finish with their own fractions, validity and weight.
+#define BT_LEAN_STEP(T)                                                                                                \
     {                                                                                                                  \
-        const int hl = qbc<K>(hlo[p]), wl = qbc<K>(wlo[p]);                                                            \
-        const bool pok = qbc<K>(okp[p]) != 0;                                                                          \
-        const float bh = qbc<K>(him[p]), bw = qbc<K>(wim[p]), aw = qbc<K>(awp[p]);                                     \
-        const float lh = bh - (float)hl, lw = bw - (float)wl;                                                          \
-        const float hh = 1.f - lh, hw = 1.f - lw;                                                                      \
+        const int r = qbc<T>(cr) + sub16;                                                                              \
+        const float4_t v1 = *reinterpret_cast<const float4_t *>(smem + r);                                             \
+        const float4_t v2 = *reinterpret_cast<const float4_t *>(smem + r + 128);                                       \
+        const float4_t v3 = *reinterpret_cast<const float4_t *>(smem + r + rw);                                        \
+        const float4_t v4 = *reinterpret_cast<const float4_t *>(smem + r + rw + 128);                                  \
+        const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
+        const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
+        R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
+    }
+            // (a window too wide to stage two rows of: the same steps with the four corners straight from global memory / L2; the owner
+            //  broadcasts four clamped byte offsets instead of one LDS address)
+#define BT_COLD_STEP(T)                                                                                                \
+    {                                                                                                                  \
+        const char *vb = reinterpret_cast<const char *>(value + lbase) + sub * 16;                                      \
+        const float4_t v1 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[0]));                 \
+        const float4_t v2 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[1]));                 \
+        const float4_t v3 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[2]));                 \
+        const float4_t v4 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[3]));                 \
+        const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
+        const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
+        R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
+    }
+#define BT_LEAN_STORE                                                                                                  \
+    {                                                                                                                  \
+        const bool pok = okp[p] != 0;                                                                                  \
+        const int hl = hlo[p], wl = wlo[p];                                                                            \
+        const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl, hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];       \
         const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;                             \
-        const bool k1 = pok && u0 && c0, k2 = pok && u0 && c1, k3 = pok && u1 && c0, k4 = pok && u1 && c1;            \
-        const int r0 = ((hl - y0) * ww + (wl - x0w)) * 128 + sub * 16, rw = ww * 128;                                  \
-        const float4_t v1 = *reinterpret_cast<const float4_t *>(smem + (k1 ? r0 : 0));                                 \
-        const float4_t v2 = *reinterpret_cast<const float4_t *>(smem + (k2 ? r0 + 128 : 0));                           \
-        const float4_t v3 = *reinterpret_cast<const float4_t *>(smem + (k3 ? r0 + rw : 0));                            \
-        const float4_t v4 = *reinterpret_cast<const float4_t *>(smem + (k4 ? r0 + rw + 128 : 0));                      \
-        const float4_t g = go[p];                                                                                      \
-        float d1 = g[0] * v1[0] + g[1] * v1[1] + g[2] * v1[2] + g[3] * v1[3];                                          \
-        float d2 = g[0] * v2[0] + g[1] * v2[1] + g[2] * v2[2] + g[3] * v2[3];                                          \
-        float d3 = g[0] * v3[0] + g[1] * v3[1] + g[2] * v3[2] + g[3] * v3[3];                                          \
-        float d4 = g[0] * v4[0] + g[1] * v4[1] + g[2] * v4[2] + g[3] * v4[3];                                          \
-        d1 = k1 ? d1 : 0.f; d2 = k2 ? d2 : 0.f; d3 = k3 ? d3 : 0.f; d4 = k4 ? d4 : 0.f;                                \
-        d1 = sum8(d1); d2 = sum8(d2); d3 = sum8(d3); d4 = sum8(d4);                                                    \
-        if (sub == 0 && (DCN ? (qok[p] && l * PT + K < DP) : pok) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
-            const long pi = DCN ? qidx[p] * DP + l * PT + K : (qidx[p] * L + l) * PT + K;                              \
+        const float d1 = (u0 && c0) ? kd[0] : 0.f, d2 = (u0 && c1) ? kd[1] : 0.f, d3 = (u1 && c0) ? kd[2] : 0.f, d4 = (u1 && c1) ? kd[3] : 0.f; \
+        if ((sub & 2) == 0 && (DCN ? (qok[p] && l * PT + kpt < DP && (inb || (!pok && yb == 0))) : inb) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
+            const long pi = DCN ? qidx[p] * DP + l * PT + kpt : (qidx[p] * L + l) * PT + kpt;                          \
             grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;         \
-            grad_loc[2 * pi] = pok ? (DCN ? dscale : (float)W) * aw * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f;         \
-            grad_loc[2 * pi + 1] = pok ? (DCN ? dscale : (float)H) * aw * (hw * (d3 - d1) + lw * (d4 - d2)) : 0.f;     \
+            *reinterpret_cast<float2_t *>(grad_loc + 2 * pi) =                                                         \
+                (float2_t){pok ? (DCN ? dscale : (float)W) * aw * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f,             \
+                           pok ? (DCN ? dscale : (float)H) * aw * (hw * (d3 - d1) + lw * (d4 - d2)) : 0.f};            \
         }                                                                                                              \
     }
             if (use_stage) {
+                const int rw = ww * 128, sub16 = sub * 16 + guard;
+                const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
+                for (int yb = 0; yb < wh; yb += hb) {
+                    // ---- B: rows yb .. yb + hb of the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave
+                    //      instruction, LDS-DMA.  The window only holds pixels of the map (its box comes from clamped corners).
+                    const int nb = min(hb + 1, wh - yb) * ww;
+                    if (yb) __syncthreads();   // the previous band has been read
+                    if (!(BT_ABL & 8)) {
+                        for (int p0 = wave * 8; p0 < nb; p0 += 32) {
+                            const int pix = min(p0 + (lane >> 3), nb - 1);
+                            const int wy = (int)(((unsigned)pix * ww_m) >> 20), wx = pix - wy * ww;
+                            const float *src = value + lbase + ((long)(y0 + yb + wy) * W + (x0w + wx)) * MD + (lane & 7) * 4;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                             (__attribute__((address_space(3))) void *)(smem + guard + p0 * 128), 16, 0, 0);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+                    BT_TICK(8)   // B: window staging
 #pragma unroll
-                for (int p = 0; p < BT_NPASS; ++p) {
-                    BT_LEAN_POINT(0) BT_LEAN_POINT(1) BT_LEAN_POINT(2) BT_LEAN_POINT(3)
+                    for (int p = 0; p < BT_NPASS; ++p) {
+                        // (this lane's OWN point: first corner's byte offset in the staged band; a point of another band reads pixel 0)
+                        const int rel = hlo[p] - y0;
+                        const bool inb = okp[p] && rel >= (yb ? yb : -1) && rel < yb + hb;
+                        const int cr = inb ? ((rel - yb) * ww + (wlo[p] - x0w)) * 128 : 0;
+                        const float4_t g = go[p];
+                        float R[4][4];
+                        BT_LEAN_STEP(0) BT_SB BT_LEAN_STEP(1) BT_SB BT_LEAN_STEP(2) BT_SB BT_LEAN_STEP(3) BT_SB
+                        float kd[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            // step j of this quad + step j + 2 of the other one (lane i <-> lane 7 - i of the query's 8), then the quad butterfly
+                            const float n0 = dpp_add<0xb1>(dpp_add<0x4e>(R[0][c] + dpp_get<0x141>(R[2][c])));
+                            const float n1 = dpp_add<0xb1>(dpp_add<0x4e>(R[1][c] + dpp_get<0x141>(R[3][c])));
+                            kd[c] = (sub & 1) ? n1 : n0;
+                        }
+                        BT_LEAN_STORE
+                    }
+                    BT_TICK(4)   // C: corner reads, grad_loc / grad_attw
                 }
             } else {
+                const int yb = 0;
 #pragma unroll
                 for (int p = 0; p < BT_NPASS; ++p) {
-                    BT_POINT(0) BT_POINT(1) BT_POINT(2) BT_POINT(3)
+                    const bool inb = okp[p] != 0;
+                    int co[4];   // (this lane's OWN point: byte offsets of its four corners, clamped into the map, inside the slice)
+                    {
+                        const int h0 = min(max(hlo[p], 0), H - 1), h1 = min(max(hlo[p] + 1, 0), H - 1);
+                        const int x0 = min(max(wlo[p], 0), W - 1), x1 = min(max(wlo[p] + 1, 0), W - 1);
+                        co[0] = inb ? (h0 * W + x0) * (int)MD * 4 : 0; co[1] = inb ? (h0 * W + x1) * (int)MD * 4 : 0;
+                        co[2] = inb ? (h1 * W + x0) * (int)MD * 4 : 0; co[3] = inb ? (h1 * W + x1) * (int)MD * 4 : 0;
+                    }
+                    const float4_t g = go[p];
+                    float R[4][4];
+                    BT_COLD_STEP(0) BT_COLD_STEP(1) BT_COLD_STEP(2) BT_COLD_STEP(3)
+                    float kd[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float n0 = dpp_add<0xb1>(dpp_add<0x4e>(R[0][c] + dpp_get<0x141>(R[2][c])));
+                        const float n1 = dpp_add<0xb1>(dpp_add<0x4e>(R[1][c] + dpp_get<0x141>(R[3][c])));
+                        kd[c] = (sub & 1) ? n1 : n0;
+                    }
+                    BT_LEAN_STORE
                 }
             }
-#undef BT_LEAN_POINT
-#undef BT_POINT
+#undef BT_LEAN_STEP
+#undef BT_LEAN_STORE
+#undef BT_COLD_STEP
             BT_TICK(4)   // C: corner reads, grad_loc / grad_attw (or direct atomics)
-            if (!use_win || (BT_ABL & 64)) continue;   // block-uniform
+            if (BT_ABL & 64) continue;
+            if (BT_GOR_LEVEL) load_gor();
 
             // ---- D: grad_value of this level: rounds of 128 window pixels ----
             __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
-            float *gflush = grad_value + lbase + l31;
-            const unsigned ww_magic = (1u << 20) / (unsigned)ww + 1u;   // pix / ww exact for pix * ww < 2^20
+            const float ww_rcp = __builtin_amdgcn_rcpf((float)ww);   // pix / ww: quotient estimate (pix < 2^23) + one correction step
             // S^T is zero whenever a round starts: zeroed once per kernel, the staged value window is wiped here, and every round
             // takes its own entries back out after the product ("un-scatter": 16 stores per lane instead of a 66 KB clear).
             __syncthreads();   // phase C's reads of the staged window are finished
             if (use_stage) {
-                const int nz = ((npix + 7) & ~7) * 8;   // float4 elements the staging wrote
-                for (int i = tid; i < nz; i += BT_THREADS) reinterpret_cast<float4_t *>(st)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                const int nz = ((min(hb + 1, wh) * ww + 7) & ~7) * 8;   // float4 elements the staging wrote (the largest band)
+                for (int i = tid; i < nz; i += BT_THREADS) reinterpret_cast<float4_t *>(smem + guard)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
                 __syncthreads();
             }
             BT_TICK(5)   // wipe + barriers
+            if (!use_win) {   // block-uniform
+                // ---- D, sparse: the (point, corner) entries {byte offset in the slice, weight} through a table in LDS (the S^T buffer),
+                //      then wave w adds the entries of ITS queries: lane (hi, l31) = channel l31 of query 2 s + hi -- two whole pixel
+                //      rows per atomic instruction.  Entry (slot, point, corner row): lane (slot, sub) owns point kpt and row sub >> 2.
+                uint2_t *toff = reinterpret_cast<uint2_t *>(smem);                       // [slot][point][corner row] -> byte offsets of its two corners
+                float2_t *twt = reinterpret_cast<float2_t *>(smem + BT_NQ * PT * 2 * 8);   //                            -> their weights
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) {
+                    const int hl = hlo[p] + (sub >> 2), wl = wlo[p];
+                    const float lh = him[p] - (float)hlo[p], lw = wim[p] - (float)wl;
+                    const float wy_ = (sub >> 2) ? lh : 1.f - lh, aw = awp[p];
+                    const bool ur = okp[p] && hl >= 0 && hl <= H - 1, k0 = ur && wl >= 0, k1 = ur && wl + 1 <= W - 1;
+                    const int o0 = (hl * W + wl) * (int)MD * 4;
+                    const int ei = ((p * BT_QPP + slot0) * PT + kpt) * 2 + (sub >> 2);
+                    toff[ei] = (uint2_t){(unsigned)(k0 ? o0 : 0), (unsigned)(k1 ? o0 + (int)MD * 4 : 0)};
+                    twt[ei] = (float2_t){k0 ? (wy_ * (1.f - lw)) * aw : 0.f, k1 ? (wy_ * lw) * aw : 0.f};
+                }
+                __syncthreads();
+                char *gsl = reinterpret_cast<char *>(grad_value + lbase) + l31 * 4;
+#pragma unroll 1
+                for (int j = 0; j < BT_NQ / 8; ++j) {
+                    const int slot = 2 * (wave * (BT_NQ / 8) + j) + hi;
+                    bool ok;
+                    const long pr = pair_of(slot, ok);
+                    const float gval = ok ? grad_out[pr * D + l31] : 0.f;
+#pragma unroll
+                    for (int e8 = 0; e8 < PT * 2; ++e8) {
+                        const uint2_t a = toff[slot * (PT * 2) + e8];
+                        const float2_t w = twt[slot * (PT * 2) + e8];
+                        if (w.x != 0.f && !(BT_ABL & 2)) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.x), w.x * gval);
+                        if (w.y != 0.f && !(BT_ABL & 2)) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.y), w.y * gval);
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < BT_NQ * PT * 2; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};   // S^T is zero again
+                BT_TICK(7)
+                continue;
+            }
             for (int base = 0; base < npix; base += BT_R) {
                 // (1) scatter: lane (query slot, sub) owns point sub & 3 of its slot's queries (both lanes sub and sub + 4 evaluated it in
                 // phase A) and two of its four corners -- the upper pair for sub < 4, the lower pair otherwise: every lane of the wave
                 // has work, 8 LDS float atomics per lane and round.  (An LDS float atomic instruction costs ~100 cycles of the wave's
                 // time whatever its lane count; ordered plain read-add-write turns of the four points were measured no faster.)
                 // Corners outside the map or the round are skipped (the un-scatter sends their zero to the row's pad column).
+                if (tid < BT_R) {
+                    const int pix = base + tid;
+                    int wy = (int)((float)pix * ww_rcp), wx = pix - wy * ww;
+                    if (wx < 0) { --wy; wx += ww; } else if (wx >= ww) { ++wy; wx -= ww; }
+                    s_poff[tid] = (unsigned)(((y0 + wy) * W + (x0w + wx)) * (int)MD) * 4u;   // (slices of 4 GiB or more do not take this kernel)
+                }
                 int sidx[BT_NPASS][2];
 #pragma unroll
                 for (int p = 0; p < BT_NPASS; ++p) {
@@ -459,17 +628,38 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const float *ap = st + hi * BT_RP + wave * 32 + l31;
                     if (!(BT_ABL & 32)) {
+                        // only the k-steps whose queries have a corner in this chunk's pixel rows: group g of 8 slots (4 k-steps) touches the
+                        // linear window pixels [(first row - y0) ww, (last row - y0 + 1) ww)
+                        const int2_t rr = rows[lane & (BT_NQ / 8 - 1)];
+                        const int glo = (rr.x - y0) * ww, ghi = (-rr.y - y0 + 1) * ww;
+                        const bool hit = rr.y <= 0 && glo < p0 + 32 && ghi > p0;
+                        const unsigned gmask = (BT_CULL ? (unsigned)__ballot(hit && lane < BT_NQ / 8) : 0xffffffffu);
 #pragma unroll
-                        for (int s2 = 0; s2 < BT_NQ / 2; ++s2)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * BT_RP], gor[s2], acc, 0, 0, 0);
+                        for (int g8 = 0; g8 < BT_NQ / 8; ++g8) {
+                            if (gmask & (1u << g8)) {
+#pragma unroll
+                                for (int s2 = 4 * g8; s2 < 4 * g8 + 4; ++s2)
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * BT_RP], gor[s2], acc, 0, 0, 0);
+                            }
+                        }
                     }
-                    // accumulator register r: pixel (r & 3) + 8 (r >> 2) + 4 hi of the chunk, channel l31
+                    // accumulator register r: pixel (r & 3) + 8 (r >> 2) + 4 hi of the chunk, channel l31.  The pixel's byte offset inside the
+                    // (batch, level, head) slice comes from the round's table (one division per pixel and round instead of one per
+                    // (pixel, lane)); a column nobody scattered into -- all columns beyond the window -- has an exactly zero sum.
+                    char *gfl = reinterpret_cast<char *>(grad_value + lbase);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pix = p0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const int wy = (int)(((unsigned)pix * ww_magic) >> 20), wx = pix - wy * ww;
-                        if (pix < npix && acc[r] != 0.f && !(BT_ABL & 1))
-                            unsafeAtomicAdd(gflush + ((long)(y0 + wy) * W + (x0w + wx)) * MD, acc[r]);
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const uint4_t po = *reinterpret_cast<const uint4_t *>(&s_poff[wave * 32 + 8 * j4 + 4 * hi]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float a = acc[4 * j4 + i];
+                            if (a != 0.f && !(BT_ABL & 1) && !((BT_ABL & 256) && (i & 1)) && !((BT_ABL & 1024) && dscale != 12345.f)) {   // (1024: the product is computed, nothing is flushed)
+                                const unsigned po_i = (BT_ABL & 512) ? (po[i] & 0xfff80u) : po[i];   // (timing only: 256 every second atomic, 512 all of them inside 1 MiB)
+                                float *dst = reinterpret_cast<float *>(gfl + (size_t)(po_i + (unsigned)l31 * 4u));
+                                if (BT_ABL & 128) *dst = a;   // (timing only: plain stores)
+                                else unsafeAtomicAdd(dst, a);
+                            }
+                        }
                     }
                 }
                 BT_TICK(7)   // MFMA + flush
@@ -514,7 +704,8 @@ int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_
 // zero-filled by the caller (it is accumulated); grad_offset / grad_mask are written completely.
 bool dcnv3_bwd_mfma_takes(const Dcnv3Geo &q)
 {
-    return q.C == 32 && q.kh * q.kw >= 1 && q.kh * q.kw <= 4 * BT_MAXL && (long)q.N * q.H * q.W * q.G * q.C < (1L << 40);
+    return q.C == 32 && q.kh * q.kw >= 1 && q.kh * q.kw <= 4 * BT_MAXL && (long)q.N * q.H * q.W * q.G * q.C < (1L << 40) &&
+           (long)q.H * q.W * q.G * q.C * 4 < (1L << 31);   // (32-bit byte offsets inside an image)
 }
 int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *mask, const float *grad_out, const Dcnv3Geo &q,
                           float offset_scale, float *grad_input, float *grad_offset, float *grad_mask, hipStream_t st)
