@@ -85,7 +85,6 @@ constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in 
 #define BT_MAXWIN_PX 8192
 #endif
 constexpr int BT_MAXWIN = BT_MAXWIN_PX;   // larger windows (a tile of coarse-level queries on a fine map: few points on many pixels): one atomic per (point, corner, channel), two whole pixel rows per wave instruction
-constexpr int BT_STAGE = (BT_NQ * BT_RP * 4) / 128;   // pixels of the S^T buffer (free during phase C): a window is staged there for the corner reads when it fits with a guard of ww + 1 pixels on either side
 constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
 constexpr size_t BT_LDS = BT_DIRECT ? BT_LDS_WIN : BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -103,6 +102,18 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float x)   // x + (
 template <int CTRL> __device__ __forceinline__ float dpp_get(float x)   // x of the lane CTRL selects
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// minimum over the wave, in a scalar register: four DPP steps inside the rows of 16 lanes (quad butterfly, half mirror, mirror), lane 15 of
+// rows 0 / 2 onto rows 1 / 3, lane 31 onto the upper half, lane 63 read out -- no LDS permutes (six dependent ds_bpermute per value before)
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_min(int x)
+{
+    return min(x, __builtin_amdgcn_update_dpp(0x7fffffff, x, CTRL, ROWS, 0xf, false));   // (lanes without a source: the identity)
+}
+__device__ __forceinline__ int wave_min(int x)
+{
+    x = dpp_min<0xb1, 0xf>(x); x = dpp_min<0x4e, 0xf>(x); x = dpp_min<0x141, 0xf>(x); x = dpp_min<0x140, 0xf>(x);
+    x = dpp_min<0x142, 0xa>(x); x = dpp_min<0x143, 0xc>(x);
+    return __builtin_amdgcn_readlane(x, 63);
 }
 // sum over the 8 lanes {8 n .. 8 n + 7}; valid in lane 8 n (quad butterfly: quad_perm [1,0,3,2], [2,3,0,1]; then row_shl:4 brings
 // the upper quad's sum down: lane i reads lane i + 4)
@@ -365,15 +376,74 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
 #if BT_DIRECT
             if (l + 1 < L) load_points(l + 1);
 #endif
+            // ---- C: per (query, point): the four corner reads and the two per-point gradients.  Nothing here depends on the block's
+            // window: it runs before the window barrier, each wave at its own pace.  The per-point gradients only need the four dot
+            // products  d_i = <grad_out, corner i>  over the 32 channels:  grad_attw = sum_i w_i d_i,
+            // grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),  grad_y = H aw (hw (d3 - d1) + lw (d4 - d2)).  The 8 lanes of a query (4 channels
+            // each) walk its four points in four steps -- the lower quad in the order 0 1 2 3, the upper quad 2 3 0 1 -- and of a point
+            // they only need the byte offsets of its four corners (clamped into the map; DPP broadcasts from the lane that owns the
+            // point): 4 x 16 bytes from global memory / L1 (a tile's window is a few KiB and is read by 64 queries) and 12 packed
+            // multiply-adds per step.  (Rounds 3-5 staged the window in LDS for this: two more barriers and a wipe per level pass, and
+            // no faster -- profiles/r05_msda_bwd_diet.txt.)  The sums over the 8 lanes are a reduce-scatter: one exchange between the
+            // quads (row_half_mirror: step t of one quad meets step t + 2 of the other -- the SAME point -- so the lower quad ends up
+            // with points 0, 1 and the upper quad with 2, 3: no selects), then a butterfly inside the quad: 24 DPP adds per query and
+            // level instead of 48.  Lanes 0, 1 of either quad own exactly the points they hold the sums of, and finish with their own
+            // fractions, validity and weight: the four points of a query leave as one 16-byte and one 32-byte piece.
+            {
+                const char *vb = reinterpret_cast<const char *>(value + lbase) + sub * 16;
+#define BT_STEP(T)                                                                                                     \
+    {                                                                                                                  \
+        const float4_t v1 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[0]));                 \
+        const float4_t v2 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[1]));                 \
+        const float4_t v3 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[2]));                 \
+        const float4_t v4 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[3]));                 \
+        const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
+        const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
+        R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
+    }
+#pragma unroll
+                for (int p = 0; p < BT_NPASS; ++p) {
+                    const bool pok = okp[p] != 0;
+                    const int hl = hlo[p], wl = wlo[p];
+                    int co[4];   // (this lane's OWN point: byte offsets of its four corners, clamped into the map, inside the slice; a rejected point reads pixel 0)
+                    {
+                        const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
+                        const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);
+                        co[0] = pok ? (h0 * W + x0) * (int)MD * 4 : 0; co[1] = pok ? (h0 * W + x1) * (int)MD * 4 : 0;
+                        co[2] = pok ? (h1 * W + x0) * (int)MD * 4 : 0; co[3] = pok ? (h1 * W + x1) * (int)MD * 4 : 0;
+                    }
+                    const float4_t g = go[p];
+                    float R[4][4];
+                    if (!(BT_ABL & 8)) { BT_STEP(0) BT_STEP(1) BT_STEP(2) BT_STEP(3) }
+                    float kd[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        // step j of this quad + step j + 2 of the other one (lane i <-> lane 7 - i of the query's 8), then the quad butterfly
+                        const float n0 = dpp_add<0xb1>(dpp_add<0x4e>(R[0][c] + dpp_get<0x141>(R[2][c])));
+                        const float n1 = dpp_add<0xb1>(dpp_add<0x4e>(R[1][c] + dpp_get<0x141>(R[3][c])));
+                        kd[c] = (sub & 1) ? n1 : n0;
+                    }
+                    const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl, hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];
+                    const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
+                    const float d1 = (u0 && c0) ? kd[0] : 0.f, d2 = (u0 && c1) ? kd[1] : 0.f, d3 = (u1 && c0) ? kd[2] : 0.f, d4 = (u1 && c1) ? kd[3] : 0.f;
+                    // MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot
+                    if ((sub & 2) == 0 && (DCN ? (qok[p] && l * PT + kpt < DP) : pok) && !(BT_ABL & 16)) {
+                        const long pi = DCN ? qidx[p] * DP + l * PT + kpt : (qidx[p] * L + l) * PT + kpt;
+                        grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;
+                        *reinterpret_cast<float2_t *>(grad_loc + 2 * pi) =
+                            (float2_t){pok ? (DCN ? dscale : (float)W) * aw * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f,
+                                       pok ? (DCN ? dscale : (float)H) * aw * (hw * (d3 - d1) + lw * (d4 - d2)) : 0.f};
+                    }
+                }
+#undef BT_STEP
+            }
+            BT_TICK(4)   // C: corner reads, grad_loc / grad_attw
             int r2 = xmin, r3 = -xmax;
 #pragma unroll
             for (int p = 0; p < BT_NPASS; ++p) rhi[p] = -rhi[p];
+            r2 = wave_min(r2); r3 = wave_min(r3);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                r2 = min(r2, __shfl_xor(r2, o)); r3 = min(r3, __shfl_xor(r3, o));
-#pragma unroll
-                for (int p = 0; p < BT_NPASS; ++p) { rlo[p] = min(rlo[p], __shfl_xor(rlo[p], o)); rhi[p] = min(rhi[p], __shfl_xor(rhi[p], o)); }
-            }
+            for (int p = 0; p < BT_NPASS; ++p) { rlo[p] = wave_min(rlo[p]); rhi[p] = wave_min(rhi[p]); }
             int r0 = rlo[0], r1 = rhi[0];
 #pragma unroll
             for (int p = 1; p < BT_NPASS; ++p) { r0 = min(r0, rlo[p]); r1 = min(r1, rhi[p]); }
@@ -391,165 +461,19 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             const int y1 = -uni(min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
             const int x0w = uni(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])));
             const int x1w = -uni(min(min(red[0][3], red[1][3]), min(red[2][3], red[3][3])));
-            if (y1 < 0) {   // no accepted point at this level (block-uniform): MSDA: all three gradients stay zero (the caller's fill)
-                if (DCN && sub == 0) {   // DCNv3 writes every slot of grad_offset / grad_mask
-#pragma unroll
-                    for (int p = 0; p < BT_NPASS; ++p)
-                        for (int K = 0; K < PT; ++K)
-                            if (qok[p] && l * PT + K < DP) {
-                                const long pi = qidx[p] * DP + l * PT + K;
-                                grad_attw[pi] = 0.f; grad_loc[2 * pi] = 0.f; grad_loc[2 * pi + 1] = 0.f;
-                            }
-                }
-                continue;
-            }
+            if (y1 < 0) continue;   // no accepted point at this level (block-uniform): nothing for grad_value
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
-            // staged window: pixel (wy, wx) at byte ((ww + 1) + wy ww + wx) 128.  The guard of ww + 1 pixels in front and behind keeps the
-            // four corner addresses of every accepted point inside the buffer (row -1 / H, column -1 / W: their sums are discarded).
-            // A window that does not fit is staged in BANDS of rows (a band of hb rows of first corners needs hb + 1 rows): phase C runs
-            // once per band for the points whose first corner row lies in it.  Wider than a band of two rows: the cold path.
-            const int guard = (ww + 1) * 128;
-            const int cap_rows = (BT_STAGE - 2 * (ww + 1) - 8) / ww;   // rows that fit
-            const bool use_stage = cap_rows >= wh || cap_rows >= 2;  // block-uniform
-            const int hb = cap_rows >= wh ? wh : cap_rows - 1;       // rows of first corners per band
             BT_TICK(3)   // window barrier
-            BT_TICK(8)   // B: window staging
-
-            // ---- C: per (query, point): the four corner reads and the two per-point gradients ----
-            // Staged window (the common case): the per-point gradients only need the four dot products  d_i = <grad_out, corner i>
-            // over the 32 channels:  grad_attw = sum_i w_i d_i,  grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),
-            // grad_y = H aw (hw (d3 - d1) + lw (d4 - d2)).  The 8 lanes of a query (4 channels each) walk its four points in four steps --
-            // the lower quad in the order 0 1 2 3, the upper quad 2 3 0 1 -- and of a point they only need the byte address of its first
-            // corner (one DPP broadcast from the lane that owns the point): 4 LDS reads and 12 packed multiply-adds per step.  The sums
-            // over the 8 lanes are a reduce-scatter: one exchange between the quads (row_half_mirror: step t of one quad meets step
-            // t + 2 of the other -- the SAME point -- so the lower quad ends up with points 0, 1 and the upper quad with 2, 3: no
-            // selects), then a butterfly inside the quad: 24 DPP adds per query and level instead of 48.  Lanes 0, 1 of either quad
-            // own exactly the points they hold the sums of, and finish with their own fractions, validity and weight.
-#define BT_LEAN_STEP(T)                                                                                                \
-    {                                                                                                                  \
-        const int r = qbc<T>(cr) + sub16;                                                                              \
-        const float4_t v1 = *reinterpret_cast<const float4_t *>(smem + r);                                             \
-        const float4_t v2 = *reinterpret_cast<const float4_t *>(smem + r + 128);                                       \
-        const float4_t v3 = *reinterpret_cast<const float4_t *>(smem + r + rw);                                        \
-        const float4_t v4 = *reinterpret_cast<const float4_t *>(smem + r + rw + 128);                                  \
-        const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
-        const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
-        R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
-    }
-            // (a window too wide to stage two rows of: the same steps with the four corners straight from global memory / L2; the owner
-            //  broadcasts four clamped byte offsets instead of one LDS address)
-#define BT_COLD_STEP(T)                                                                                                \
-    {                                                                                                                  \
-        const char *vb = reinterpret_cast<const char *>(value + lbase) + sub * 16;                                      \
-        const float4_t v1 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[0]));                 \
-        const float4_t v2 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[1]));                 \
-        const float4_t v3 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[2]));                 \
-        const float4_t v4 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[3]));                 \
-        const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
-        const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
-        R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
-    }
-#define BT_LEAN_STORE                                                                                                  \
-    {                                                                                                                  \
-        const bool pok = okp[p] != 0;                                                                                  \
-        const int hl = hlo[p], wl = wlo[p];                                                                            \
-        const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl, hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];       \
-        const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;                             \
-        const float d1 = (u0 && c0) ? kd[0] : 0.f, d2 = (u0 && c1) ? kd[1] : 0.f, d3 = (u1 && c0) ? kd[2] : 0.f, d4 = (u1 && c1) ? kd[3] : 0.f; \
-        if ((sub & 2) == 0 && (DCN ? (qok[p] && l * PT + kpt < DP && (inb || (!pok && yb == 0))) : inb) && !(BT_ABL & 16)) {   /* MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot */ \
-            const long pi = DCN ? qidx[p] * DP + l * PT + kpt : (qidx[p] * L + l) * PT + kpt;                          \
-            grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;         \
-            *reinterpret_cast<float2_t *>(grad_loc + 2 * pi) =                                                         \
-                (float2_t){pok ? (DCN ? dscale : (float)W) * aw * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f,             \
-                           pok ? (DCN ? dscale : (float)H) * aw * (hw * (d3 - d1) + lw * (d4 - d2)) : 0.f};            \
-        }                                                                                                              \
-    }
-            if (use_stage) {
-                const int rw = ww * 128, sub16 = sub * 16 + guard;
-                const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
-                for (int yb = 0; yb < wh; yb += hb) {
-                    // ---- B: rows yb .. yb + hb of the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave
-                    //      instruction, LDS-DMA.  The window only holds pixels of the map (its box comes from clamped corners).
-                    const int nb = min(hb + 1, wh - yb) * ww;
-                    if (yb) __syncthreads();   // the previous band has been read
-                    if (!(BT_ABL & 8)) {
-                        for (int p0 = wave * 8; p0 < nb; p0 += 32) {
-                            const int pix = min(p0 + (lane >> 3), nb - 1);
-                            const int wy = (int)(((unsigned)pix * ww_m) >> 20), wx = pix - wy * ww;
-                            const float *src = value + lbase + ((long)(y0 + yb + wy) * W + (x0w + wx)) * MD + (lane & 7) * 4;
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                             (__attribute__((address_space(3))) void *)(smem + guard + p0 * 128), 16, 0, 0);
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __syncthreads();
-                    BT_TICK(8)   // B: window staging
-#pragma unroll
-                    for (int p = 0; p < BT_NPASS; ++p) {
-                        // (this lane's OWN point: first corner's byte offset in the staged band; a point of another band reads pixel 0)
-                        const int rel = hlo[p] - y0;
-                        const bool inb = okp[p] && rel >= (yb ? yb : -1) && rel < yb + hb;
-                        const int cr = inb ? ((rel - yb) * ww + (wlo[p] - x0w)) * 128 : 0;
-                        const float4_t g = go[p];
-                        float R[4][4];
-                        BT_LEAN_STEP(0) BT_SB BT_LEAN_STEP(1) BT_SB BT_LEAN_STEP(2) BT_SB BT_LEAN_STEP(3) BT_SB
-                        float kd[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            // step j of this quad + step j + 2 of the other one (lane i <-> lane 7 - i of the query's 8), then the quad butterfly
-                            const float n0 = dpp_add<0xb1>(dpp_add<0x4e>(R[0][c] + dpp_get<0x141>(R[2][c])));
-                            const float n1 = dpp_add<0xb1>(dpp_add<0x4e>(R[1][c] + dpp_get<0x141>(R[3][c])));
-                            kd[c] = (sub & 1) ? n1 : n0;
-                        }
-                        BT_LEAN_STORE
-                    }
-                    BT_TICK(4)   // C: corner reads, grad_loc / grad_attw
-                }
-            } else {
-                const int yb = 0;
-#pragma unroll
-                for (int p = 0; p < BT_NPASS; ++p) {
-                    const bool inb = okp[p] != 0;
-                    int co[4];   // (this lane's OWN point: byte offsets of its four corners, clamped into the map, inside the slice)
-                    {
-                        const int h0 = min(max(hlo[p], 0), H - 1), h1 = min(max(hlo[p] + 1, 0), H - 1);
-                        const int x0 = min(max(wlo[p], 0), W - 1), x1 = min(max(wlo[p] + 1, 0), W - 1);
-                        co[0] = inb ? (h0 * W + x0) * (int)MD * 4 : 0; co[1] = inb ? (h0 * W + x1) * (int)MD * 4 : 0;
-                        co[2] = inb ? (h1 * W + x0) * (int)MD * 4 : 0; co[3] = inb ? (h1 * W + x1) * (int)MD * 4 : 0;
-                    }
-                    const float4_t g = go[p];
-                    float R[4][4];
-                    BT_COLD_STEP(0) BT_COLD_STEP(1) BT_COLD_STEP(2) BT_COLD_STEP(3)
-                    float kd[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float n0 = dpp_add<0xb1>(dpp_add<0x4e>(R[0][c] + dpp_get<0x141>(R[2][c])));
-                        const float n1 = dpp_add<0xb1>(dpp_add<0x4e>(R[1][c] + dpp_get<0x141>(R[3][c])));
-                        kd[c] = (sub & 1) ? n1 : n0;
-                    }
-                    BT_LEAN_STORE
-                }
-            }
-#undef BT_LEAN_STEP
-#undef BT_LEAN_STORE
-#undef BT_COLD_STEP
-            BT_TICK(4)   // C: corner reads, grad_loc / grad_attw (or direct atomics)
             if (BT_ABL & 64) continue;
             if (BT_GOR_LEVEL) load_gor();
 
             // ---- D: grad_value of this level: rounds of 128 window pixels ----
             __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
             const float ww_rcp = __builtin_amdgcn_rcpf((float)ww);   // pix / ww: quotient estimate (pix < 2^23) + one correction step
-            // S^T is zero whenever a round starts: zeroed once per kernel, the staged value window is wiped here, and every round
-            // takes its own entries back out after the product ("un-scatter": 16 stores per lane instead of a 66 KB clear).
-            __syncthreads();   // phase C's reads of the staged window are finished
-            if (use_stage) {
-                const int nz = ((min(hb + 1, wh) * ww + 7) & ~7) * 8;   // float4 elements the staging wrote (the largest band)
-                for (int i = tid; i < nz; i += BT_THREADS) reinterpret_cast<float4_t *>(smem + guard)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-                __syncthreads();
-            }
+            // S^T is zero whenever a round starts: zeroed once per kernel, and every round takes its own entries back out after the
+            // product ("un-scatter": a few stores per lane instead of a 33 KB clear).
             BT_TICK(5)   // wipe + barriers
             if (!use_win) {   // block-uniform
                 // ---- D, sparse: the (point, corner) entries {byte offset in the slice, weight} through a table in LDS (the S^T buffer),
