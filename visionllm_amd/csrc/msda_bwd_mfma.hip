@@ -1,23 +1,28 @@
-// MSDA backward for the encoder self-attention case (queries == pyramid pixels, Lq == S, D = 32, P = 4), generation 2:
-// grad_value through the matrix cores.
+// MSDA backward for the encoder self-attention case (queries == pyramid pixels, Lq == S, D = 32, P = 4): grad_value through the
+// matrix cores.  Follows ms_deform_im2col_cuda.cuh:87-161 (col2im bilinear: grad_value scatter, grad_sampling_loc, grad_attn_weight)
+// and the reductions of :301-360.
 //
-// What the phase clock of msda_bwd_tiled.hip showed (profiles/r03_msda_bwd_phases.txt): 86 % of its 22 ms is the phase that
-// accumulates grad_value in LDS with ds_add_f32 -- 65 536 lane-atomics per (query tile, level), and the LDS retires a float
-// atomic every ~2 cycles per LANE, whatever the addresses.  But the scatter factors: for a tile of 128 queries and a window
-// of pixels
+// The scatter factors: for a tile of queries and a window of pixels of one (batch, level, head)
 //      grad_value[pix, ch] += sum_q  S[pix, q] * grad_out[q, ch],     S[pix, q] = sum over the 16 (point, corner) pairs of
 //                                                                     query q that land on pix of  attention weight x bilinear weight
-// -- the channel does not enter S.  So per (tile, level):
-//   (1) S^T [128 queries][128 window pixels] is built in LDS with 2 048 lane-atomics (one per (query, point, corner): 32x fewer),
-//   (2) a wave multiplies a 32-pixel chunk of it with grad_out [128 x 32] on v_mfma_f32_32x32x2_f32 (exact fp32; 64 steps of
-//       k = 2 queries; the B operand -- grad_out of the tile -- stays in 64 registers for all levels and rounds of the item),
-//   (3) and adds its 32 x 32 result to grad_value with one atomic per (pixel, channel), a wave instruction covering two whole
-//       128-byte pixel rows.
-// Windows larger than 128 pixels take several rounds of (1)-(3); beyond 1024 pixels (far-away samples) the level falls
-// back to direct global atomics per (point, corner, channel).  grad_sampling_loc and grad_attn_weight are computed as
-// before (value corners from global memory / L2, one owner per element, plain stores).
+// -- the channel does not enter S (round 2 accumulated the window with one LDS float atomic per (point, corner, CHANNEL): 22 ms).
 //
-// Round 4: the SAME kernel serves the DCNv3 backward for group channels 32 (template flag DCN; dcnv3_im2col_cuda.cuh:86-146, 279-857):
+// A persistent block of 4 waves walks items = (batch, head, tile of 8 x 8 queries); three blocks per CU (33 KiB of LDS, <= 168
+// registers).  Per item: grad_out of the tile as the B operand of the product, 32 registers for all levels.  Per level:
+//   A  a lane evaluates ITS point of its queries (8 lanes per query: lane K of the lower quad owns point K, of the upper quad point
+//      K + 2), locations / weights straight from global memory, requested one level ahead;
+//   C  grad_sampling_loc / grad_attn_weight: the 8 lanes of a query (4 channels each) walk its four points, 4 x 16 bytes per step from
+//      global memory / L1, the dot products reduce-scattered over the 8 lanes by DPP -- before the window barrier, every wave at its
+//      own pace (details at the code);
+//   -- the exact bounding window of the tile's corners: wave minima by DPP, one barrier --
+//   D  rounds of 128 window pixels: (1) S^T [64 queries][128 pixels] in LDS with one lane-atomic per (query, point, corner),
+//      (2) a wave multiplies ITS 32-pixel chunk with grad_out [64 x 32] on v_mfma_f32_32x32x2_f32 (exact fp32), skipping the
+//      groups of 8 queries that have no corner in its pixel rows and zeroing the entries as it reads them, (3) and adds the
+//      32 x 32 result to grad_value with one atomic per (pixel, channel), a wave instruction covering two whole 128-byte pixel
+//      rows at byte offsets from a per-round table.  One barrier per round (two between rounds of one level).
+//      Windows beyond 8192 pixels: the (point, corner) entries through a table in LDS and one atomic per (entry, channel).
+//
+// The SAME kernel serves the DCNv3 backward for group channels 32 (template flag DCN; dcnv3_im2col_cuda.cuh:86-146, 279-857):
 // a DCNv3 call is this operator with ONE value map (the input), heads = groups, queries = output pixels, attention weights = the
 // mask, and kh * kw sampling points per query that are run as ceil(kh kw / 4) pseudo-levels of 4 points (3 for the 3 x 3 kernel;
 // slots beyond kh kw get a rejected location).  What differs is confined to four places: the geometry set-up, where a point's
@@ -25,26 +30,23 @@
 // lands in the same cell as in the reference), the scale of the location gradient (offset_scale instead of W / H), and the
 // indexing of the three per-point outputs.
 //
-// Follows ms_deform_im2col_cuda.cuh:87-161 (col2im bilinear: grad_value scatter, grad_sampling_loc, grad_attn_weight) and
-// the reductions of :301-360.  Summation order differs from the reference's atomics (as every atomic scatter does); tests
-// compare against the oracle with the tolerance of the other backward kernels.
+// Summation order differs from the reference's atomics (as every atomic scatter does); tests compare against the oracle with the
+// tolerance of the other backward kernels.  History and measurements: NOTES/r05.md section 8, profiles/r05_msda_bwd_diet.txt
+// (rounds 3-4: 8 x 16 tiles, 2 blocks per CU, window staged in LDS for phase C, per-level hand-over through LDS: 4.05 ms at
+// cfg 4 / B = 8; now 2.65 ms).
 #include "common.hpp"
 #include "kernels.hpp"
 #include "msda_sample.hpp"
 #include "dcnv3_geo.hpp"
 
-// Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no direct (large-window) atomics, 4: no S scatter,
-// 8: no value corner reads (zeros), 16: no grad_loc / grad_attw stores, 32: no MFMA, 64: no grad_value rounds at all,
-// 128: the flush as plain stores.
+// Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no sparse-path atomics, 4: no S scatter,
+// 8: no value corner reads, 16: no grad_loc / grad_attw stores (phase C becomes dead code), 32: no MFMA, 64: no grad_value rounds at
+// all, 128: the flush as plain stores, 256: every second flush atomic, 512: all of them inside 1 MiB, 1024: product computed, nothing
+// flushed.
 #ifndef BT_ABL
 #define BT_ABL 0
 #endif
 
-#ifdef BT_SCHED_FENCE    // keeps the scheduler from hoisting one point's LDS reads over the previous point (register pressure)
-#define BT_SB __builtin_amdgcn_sched_barrier(0);
-#else
-#define BT_SB
-#endif
 #ifdef BT_PROF
 #define BT_TICK(slot) { const unsigned now__ = (unsigned)__builtin_amdgcn_s_memtime(); pacc[slot] += now__ - tprev; tprev = now__; }
 #elif defined(BT_MARKS)
@@ -69,14 +71,11 @@ constexpr int BT_MAXL = 8;
 #ifndef BT_BLOCKS_PER_CU
 #define BT_BLOCKS_PER_CU 3
 #endif
-#ifndef BT_DIRECT        // 1: a lane loads its own point's location / weight from global memory (no hand-over through LDS, two barriers
-#define BT_DIRECT 1      //    per level fewer); 0: rounds 3-4 (two loader threads per query, s_loc / s_aw)
+#ifndef BT_STAGE_C       // 1: a window of up to ~130 pixels is copied into LDS (LDS-DMA, behind the first round's scatter) and phase C reads its
+#define BT_STAGE_C 1     //    corners there, after the rounds (128 B / clock instead of the L1's 64); 0: phase C from global memory, before the barrier
 #endif
 #ifndef BT_CULL          // 1: the grad_value product skips the k-steps (groups of 8 query slots) that have no corner in the wave's 32 pixels
 #define BT_CULL 1
-#endif
-#ifndef BT_GOR_LEVEL     // 1: the grad_out operand of the grad_value product is re-read (L2) per level behind phase C instead of living
-#define BT_GOR_LEVEL 0   //    in BT_NQ / 2 registers across the whole item
 #endif
 constexpr int BT_TH = 8, BT_TW = BT_TILE_W, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
 constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
@@ -85,8 +84,9 @@ constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in 
 #define BT_MAXWIN_PX 8192
 #endif
 constexpr int BT_MAXWIN = BT_MAXWIN_PX;   // larger windows (a tile of coarse-level queries on a fine map: few points on many pixels): one atomic per (point, corner, channel), two whole pixel rows per wave instruction
-constexpr size_t BT_LDS_WIN = (size_t)BT_NQ * BT_RP * 4 + 16, BT_LDS_LOC = (size_t)BT_NQ * 4 * 8, BT_LDS_AW = (size_t)BT_NQ * 4 * 4;
-constexpr size_t BT_LDS = BT_DIRECT ? BT_LDS_WIN : BT_LDS_WIN + BT_LDS_LOC + BT_LDS_AW;
+constexpr size_t BT_LDS_ST = (size_t)BT_NQ * BT_RP * 4 + 16;   // S^T
+constexpr int BT_STG_PX = BT_STAGE_C ? 150 : 0;                 // staged window incl. its guards: 18.75 KiB (3 blocks per CU: 3 x 52 KiB, whatever the allocation granule)
+constexpr size_t BT_LDS = BT_LDS_ST + (size_t)BT_STG_PX * 128;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef int int2_t __attribute__((ext_vector_type(2)));
 
@@ -138,8 +138,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
     const int DP = DCN ? dq.kh * dq.kw : 0;   // DCNv3: sampling points per (pixel, group); L = (DP + 3) / 4 pseudo-levels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *st = reinterpret_cast<float *>(smem);                                   // S^T [128 queries][BT_RP]: weight of query q on window pixel p of this round
-    float2_t *s_loc = reinterpret_cast<float2_t *>(smem + BT_LDS_WIN);             // [128 queries][4 points]
-    float *s_aw = reinterpret_cast<float *>(smem + BT_LDS_WIN + BT_LDS_LOC);       // [128 queries][4 points]
     __shared__ int s_H[BT_MAXL], s_W[BT_MAXL], s_q0[BT_MAXL], s_tc[BT_MAXL + 1];
     __shared__ long s_v0[BT_MAXL];
     __shared__ int2_t s_rows[2][BT_NQ / 8];
@@ -242,8 +240,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 gor[s2] = ok ? v : 0.f;
             }
         };
-        if (!BT_GOR_LEVEL) load_gor();
-#if BT_DIRECT
+        load_gor();
         // this lane's point (kpt) of its query of pass p at level l: 8 + 4 bytes straight from global memory (the 4 points of a query
         // are one 32-byte / 16-byte piece; lanes sub and sub + 4 read the same words), requested one level ahead.
         // DCNv3: offset -> location in input pixels, the reference's arithmetic (dcnv3_im2col_cuda.cuh:300-334: p0 = centre of the
@@ -277,70 +274,13 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             }
         };
         load_points(0);
-#else
-        bool lq_ok, aq_ok;
-        const long lq_pair = pair_of(tid >> 1, lq_ok);
-        const long aq_pair = pair_of(tid & (BT_NQ - 1), aq_ok);
-        const bool lthr = tid < BT_NQ * 2;
-        // locations (x, y) of two points of a query per thread (tid < 256) and the 4 weights of a query (tid < 128) of level l.
-        // DCNv3: offsets -> locations in input pixels, the reference's arithmetic (dcnv3_im2col_cuda.cuh:300-334: p0 = centre of the
-        // kernel footprint, point (i, j) of the kw x kh grid in w-major order); a slot beyond kh * kw gets (-2, -2): rejected.
-        float dp0w = 0.f, dp0h = 0.f;
-        if (DCN) {
-            const int slot = tid >> 1, y = ty * BT_TH + slot / BT_TW, x = tx * BT_TW + slot % BT_TW;
-            const int p0_w = ((dq.dw * (dq.kw - 1)) >> 1) - dq.pw + x * dq.sw, p0_h = ((dq.dh * (dq.kh - 1)) >> 1) - dq.ph + y * dq.sh;
-            // (every product rounded on its own -- mul_rn, msda_sample.hpp: the backend would fuse mul + add into one fma, and one ulp
-            //  of a location of ~100 pixels is 8e-6 of a pixel: visible in the bilinear weights)
-            dp0w = (float)p0_w - mul_rn((float)((dq.dw * (dq.kw - 1)) >> 1), dscale);
-            dp0h = (float)p0_h - mul_rn((float)((dq.dh * (dq.kh - 1)) >> 1), dscale);
-        }
-        auto load_loc = [&](int l) -> float4_t {
-            if (!DCN) return *reinterpret_cast<const float4_t *>(loc + (lq_pair * L + l) * (PT * 2) + (tid & 1) * 4);
-            float4_t r = {-2.f, -2.f, -2.f, -2.f};
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int j = l * PT + (tid & 1) * 2 + e;
-                if (j < DP) {
-                    const float2_t o2 = *reinterpret_cast<const float2_t *>(loc + (lq_pair * DP + j) * 2);
-                    const int i = j / dq.kh, jj = j - i * dq.kh;
-                    r[2 * e] = dp0w + mul_rn((float)(i * dq.dw) + o2.x, dscale);
-                    r[2 * e + 1] = dp0h + mul_rn((float)(jj * dq.dh) + o2.y, dscale);
-                }
-            }
-            return r;
-        };
-        auto load_aw = [&](int l) -> float4_t {
-            if (!DCN) return *reinterpret_cast<const float4_t *>(attw + (aq_pair * L + l) * PT);
-            float4_t r = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (l * PT + e < DP) r[e] = attw[aq_pair * DP + l * PT + e];
-            return r;
-        };
-        float4_t nloc = {0.f, 0.f, 0.f, 0.f};
-        if (lthr) nloc = load_loc(0);
-        float4_t naw = {0.f, 0.f, 0.f, 0.f};
-        if (tid < BT_NQ) naw = load_aw(0);
-
-#endif
 
         BT_TICK(0)   // item set-up: decode, grad_output / first level's locations requested
         for (int l = 0; l < L; ++l) {
             const int H = uni(s_H[l]), W = uni(s_W[l]);
             const long lbase = (b * (long)S + uni(s_v0[l])) * MD + (long)m * D;   // (batch, level, head) origin, channel 0
-            const float *vl = value + lbase + sub * 4;
 
-#if !BT_DIRECT
-            __syncthreads();   // previous level / item: every read of s_loc, s_aw, gwin, s_red is finished
-            if (lthr) reinterpret_cast<float4_t *>(s_loc)[tid] = nloc;
-            if (tid < BT_NQ) reinterpret_cast<float4_t *>(s_aw)[tid] = naw;
-            if (l + 1 < L) {
-                if (lthr) nloc = load_loc(l + 1);
-                if (tid < BT_NQ) naw = load_aw(l + 1);
-            }
-            __syncthreads();
-#endif
-            BT_TICK(1)   // two barriers around the hand-over of this level's locations / weights
+            BT_TICK(1)
 
             // ---- A: this lane's point (kpt) of each of its 4 queries; exact bounding window of all corners ----
             float him[BT_NPASS], wim[BT_NPASS], awp[BT_NPASS];
@@ -349,14 +289,8 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             int rlo[BT_NPASS], rhi[BT_NPASS];   // rows of the corners of this lane's point per pass: (wave, pass) = one group of 8 query slots
 #pragma unroll
             for (int p = 0; p < BT_NPASS; ++p) {
-                const int slot = p * BT_QPP + slot0;
-#if BT_DIRECT
                 const float2_t xy = nloc[p];
                 awp[p] = naw[p];
-#else
-                const float2_t xy = s_loc[slot * PT + kpt];
-                awp[p] = s_aw[slot * PT + kpt];
-#endif
                 SamplePoint<float> sp;
                 if (DCN) {   // xy is the location in input pixels already; acceptance and floor as dcnv3_im2col_cuda.cuh:335-336, 92-93
                     sp.h_im = xy.y; sp.w_im = xy.x;
@@ -373,9 +307,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     rlo[p] = h0; rhi[p] = h1; xmin = min(xmin, x0); xmax = max(xmax, x1);
                 }
             }
-#if BT_DIRECT
             if (l + 1 < L) load_points(l + 1);
-#endif
             // ---- C: per (query, point): the four corner reads and the two per-point gradients.  Nothing here depends on the block's
             // window: it runs before the window barrier, each wave at its own pace.  The per-point gradients only need the four dot
             // products  d_i = <grad_out, corner i>  over the 32 channels:  grad_attw = sum_i w_i d_i,
@@ -389,14 +321,26 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             // with points 0, 1 and the upper quad with 2, 3: no selects), then a butterfly inside the quad: 24 DPP adds per query and
             // level instead of 48.  Lanes 0, 1 of either quad own exactly the points they hold the sums of, and finish with their own
             // fractions, validity and weight: the four points of a query leave as one 16-byte and one 32-byte piece.
-            {
+            auto phase_c = [&](auto staged_tag, int wy0, int wx0, int www) {
+                constexpr bool STG = decltype(staged_tag)::value;
                 const char *vb = reinterpret_cast<const char *>(value + lbase) + sub * 16;
+                // staged: pixel (wy, wx) of the window at byte BT_LDS_ST + ((www + 1) + wy www + wx) 128.  The guard of www + 1 pixels in
+                // front and behind keeps the four corner addresses of every accepted point inside the buffer (row -1 / H, column
+                // -1 / W: their sums are discarded below); ONE broadcast per step: the first corner's address
+                const int rw = www * 128, sub16 = sub * 16 + (int)BT_LDS_ST + (www + 1) * 128;
 #define BT_STEP(T)                                                                                                     \
     {                                                                                                                  \
-        const float4_t v1 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[0]));                 \
-        const float4_t v2 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[1]));                 \
-        const float4_t v3 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[2]));                 \
-        const float4_t v4 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[3]));                 \
+        float4_t v1, v2, v3, v4;                                                                                       \
+        if (STG) {                                                                                                     \
+            const int r = qbc<T>(co[0]) + sub16;                                                                       \
+            v1 = *reinterpret_cast<const float4_t *>(smem + r); v2 = *reinterpret_cast<const float4_t *>(smem + r + 128); \
+            v3 = *reinterpret_cast<const float4_t *>(smem + r + rw); v4 = *reinterpret_cast<const float4_t *>(smem + r + rw + 128); \
+        } else {                                                                                                       \
+            v1 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[0]));                            \
+            v2 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[1]));                            \
+            v3 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[2]));                            \
+            v4 = *reinterpret_cast<const float4_t *>(vb + (size_t)(unsigned)qbc<T>(co[3]));                            \
+        }                                                                                                              \
         const float2_t a1 = g.hi * v1.hi + g.lo * v1.lo, a2 = g.hi * v2.hi + g.lo * v2.lo;                             \
         const float2_t a3 = g.hi * v3.hi + g.lo * v3.lo, a4 = g.hi * v4.hi + g.lo * v4.lo;                             \
         R[T][0] = a1.x + a1.y; R[T][1] = a2.x + a2.y; R[T][2] = a3.x + a3.y; R[T][3] = a4.x + a4.y;                    \
@@ -406,7 +350,8 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     const bool pok = okp[p] != 0;
                     const int hl = hlo[p], wl = wlo[p];
                     int co[4];   // (this lane's OWN point: byte offsets of its four corners, clamped into the map, inside the slice; a rejected point reads pixel 0)
-                    {
+                    if (STG) co[0] = pok ? ((hl - wy0) * www + (wl - wx0)) * 128 : 0;
+                    else {
                         const int h0 = min(max(hl, 0), H - 1), h1 = min(max(hl + 1, 0), H - 1);
                         const int x0 = min(max(wl, 0), W - 1), x1 = min(max(wl + 1, 0), W - 1);
                         co[0] = pok ? (h0 * W + x0) * (int)MD * 4 : 0; co[1] = pok ? (h0 * W + x1) * (int)MD * 4 : 0;
@@ -436,7 +381,8 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     }
                 }
 #undef BT_STEP
-            }
+            };
+            if (!BT_STAGE_C) phase_c(std::false_type{}, 0, 0, 0);
             BT_TICK(4)   // C: corner reads, grad_loc / grad_attw
             int r2 = xmin, r3 = -xmax;
 #pragma unroll
@@ -461,20 +407,34 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             const int y1 = -uni(min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
             const int x0w = uni(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])));
             const int x1w = -uni(min(min(red[0][3], red[1][3]), min(red[2][3], red[3][3])));
-            if (y1 < 0) continue;   // no accepted point at this level (block-uniform): nothing for grad_value
             const int wh = y1 - y0 + 1, ww = x1w - x0w + 1;
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
+            // phase C from LDS: the window fits the staging buffer with its guards (block-uniform)
+            const bool staged = BT_STAGE_C && y1 >= 0 && ((npix + 7) & ~7) + 2 * (ww + 1) <= BT_STG_PX;
+            bool stage_waited = false;
             BT_TICK(3)   // window barrier
-            if (BT_ABL & 64) continue;
-            if (BT_GOR_LEVEL) load_gor();
+            do {
+            if (y1 < 0) break;   // no accepted point at this level (block-uniform): nothing for grad_value
+            if (staged && !(BT_ABL & 8)) {
+                // the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave instruction, LDS-DMA; it only holds
+                // pixels of the map (its box comes from clamped corners).  Waited for in front of the first round's barrier.
+                const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
+                for (int p0 = wave * 8; p0 < npix; p0 += 32) {
+                    const int pix = min(p0 + (lane >> 3), npix - 1);
+                    const int wy = (int)(((unsigned)pix * ww_m) >> 20), wx = pix - wy * ww;
+                    const float *src = value + lbase + ((long)(y0 + wy) * W + (x0w + wx)) * MD + (lane & 7) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(smem + BT_LDS_ST + (ww + 1) * 128 + p0 * 128), 16, 0, 0);
+                }
+            }
+            if (BT_ABL & 64) break;
 
             // ---- D: grad_value of this level: rounds of 128 window pixels ----
             __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
             const float ww_rcp = __builtin_amdgcn_rcpf((float)ww);   // pix / ww: quotient estimate (pix < 2^23) + one correction step
-            // S^T is zero whenever a round starts: zeroed once per kernel, and every round takes its own entries back out after the
-            // product ("un-scatter": a few stores per lane instead of a 33 KB clear).
-            BT_TICK(5)   // wipe + barriers
+            // S^T is zero whenever a round starts: zeroed once per kernel, and a wave zeroes the entries of its 32 columns as it feeds
+            // them to the matrix core (the groups it skips have no entry there).
             if (!use_win) {   // block-uniform
                 // ---- D, sparse: the (point, corner) entries {byte offset in the slice, weight} through a table in LDS (the S^T buffer),
                 //      then wave w adds the entries of ITS queries: lane (hi, l31) = channel l31 of query 2 s + hi -- two whole pixel
@@ -492,6 +452,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     toff[ei] = (uint2_t){(unsigned)(k0 ? o0 : 0), (unsigned)(k1 ? o0 + (int)MD * 4 : 0)};
                     twt[ei] = (float2_t){k0 ? (wy_ * (1.f - lw)) * aw : 0.f, k1 ? (wy_ * lw) * aw : 0.f};
                 }
+                if (staged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stage_waited = true; }
                 __syncthreads();
                 char *gsl = reinterpret_cast<char *>(grad_value + lbase) + l31 * 4;
 #pragma unroll 1
@@ -511,7 +472,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 __syncthreads();
                 for (int i = tid; i < BT_NQ * PT * 2; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};   // S^T is zero again
                 BT_TICK(7)
-                continue;
+                break;
             }
             for (int base = 0; base < npix; base += BT_R) {
                 // (1) scatter: lane (query slot, sub) owns point sub & 3 of its slot's queries (both lanes sub and sub + 4 evaluated it in
@@ -525,7 +486,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     if (wx < 0) { --wy; wx += ww; } else if (wx >= ww) { ++wy; wx -= ww; }
                     s_poff[tid] = (unsigned)(((y0 + wy) * W + (x0w + wx)) * (int)MD) * 4u;   // (slices of 4 GiB or more do not take this kernel)
                 }
-                int sidx[BT_NPASS][2];
 #pragma unroll
                 for (int p = 0; p < BT_NPASS; ++p) {
                     const int hl = hlo[p] + (sub >> 2), wl = wlo[p];          // this lane's corner row
@@ -534,14 +494,13 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     const bool ur = okp[p] && hl >= 0 && hl <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
                     const int row = (p * BT_QPP + slot0) * BT_RP;
                     const int i1 = (hl - y0) * ww + (wl - x0w) - base, i2 = i1 + 1;
-                    sidx[p][0] = row + ((ur && c0 && (unsigned)i1 < (unsigned)BT_R) ? i1 : BT_R);
-                    sidx[p][1] = row + ((ur && c1 && (unsigned)i2 < (unsigned)BT_R) ? i2 : BT_R);
-                    // (predicated, not redirected: atomics of several lanes on one pad word would serialise)
+                    // (predicated, not redirected to a pad word: atomics of several lanes on one word would serialise)
                     if (!(BT_ABL & 4)) {
-                        if (sidx[p][0] != row + BT_R) __hip_atomic_fetch_add(st3 + sidx[p][0], (wy_ * (1.f - lw)) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (sidx[p][1] != row + BT_R) __hip_atomic_fetch_add(st3 + sidx[p][1], (wy_ * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ur && c0 && (unsigned)i1 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i1, (wy_ * (1.f - lw)) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ur && c1 && (unsigned)i2 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i2, (wy_ * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
+                if (staged && !stage_waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stage_waited = true; }   // this wave's part of the window has landed
                 __syncthreads();
                 BT_TICK(6)   // scatter + barrier
                 // (2) this wave's 32-pixel chunk x grad_out on the matrix cores, (3) atomics straight from the accumulator layout
@@ -550,7 +509,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     f32x16_t acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    const float *ap = st + hi * BT_RP + wave * 32 + l31;
+                    float *ap = st + hi * BT_RP + wave * 32 + l31;   // (this wave is the only reader of its 32 columns: it zeroes what it has read)
                     if (!(BT_ABL & 32)) {
                         // only the k-steps whose queries have a corner in this chunk's pixel rows: group g of 8 slots (4 k-steps) touches the
                         // linear window pixels [(first row - y0) ww, (last row - y0 + 1) ww)
@@ -562,8 +521,11 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                         for (int g8 = 0; g8 < BT_NQ / 8; ++g8) {
                             if (gmask & (1u << g8)) {
 #pragma unroll
-                                for (int s2 = 4 * g8; s2 < 4 * g8 + 4; ++s2)
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * BT_RP], gor[s2], acc, 0, 0, 0);
+                                for (int s2 = 4 * g8; s2 < 4 * g8 + 4; ++s2) {
+                                    const float sv = ap[2 * s2 * BT_RP];
+                                    ap[2 * s2 * BT_RP] = 0.f;
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, gor[s2], acc, 0, 0, 0);
+                                }
                             }
                         }
                     }
@@ -587,14 +549,20 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     }
                 }
                 BT_TICK(7)   // MFMA + flush
-                __syncthreads();   // every wave has read S^T
-#pragma unroll
-                for (int p = 0; p < BT_NPASS; ++p) { st[sidx[p][0]] = 0.f; st[sidx[p][1]] = 0.f; }
-                BT_TICK(11)   // barrier + un-scatter
+                if (base + BT_R < npix) __syncthreads();   // another round: every wave has read (and zeroed) its columns before the next scatter
+                BT_TICK(11)
             }
 #ifdef BT_PROF
             pacc[9] += 1; pacc[10] += (unsigned)npix;
 #endif
+            } while (0);
+            if (BT_STAGE_C) {
+                if (staged) {
+                    if (!stage_waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (no round ran: ablation builds only)
+                    phase_c(std::true_type{}, y0, x0w, ww);
+                } else phase_c(std::false_type{}, 0, 0, 0);
+                BT_TICK(4)
+            }
         }
     }
 #ifdef BT_PROF
