@@ -26,8 +26,8 @@ e0.record(); f(); e1.record(); torch.cuda.synchronize()
 print(f"kernel {e0.elapsed_time(e1):.3f} ms")
 L.bt_abl_prof(buf)
 if "mfma" in name:
-    names = ["item set-up (+ grad_out operand)", "level hand-over (2 barriers)", "A points + wave reduction", "window barrier", "C corner reads / grad_loc / grad_attw",
-             "D wipe staged window + barriers", "D scatter + barrier", "D MFMA + flush atomics", "B value window -> LDS (DMA + wait + barrier)", "-", "-", "D barrier + un-scatter"]
+    names = ["item set-up (+ grad_out operand)", "level loop top", "A points", "window barrier", "C corner reads / grad_loc / grad_attw (+ wave minima)",
+             "-", "D offset table + scatter + barrier", "D MFMA + flush atomics", "-", "-", "-", "D barrier between rounds"]
 else:
     names = ["item set-up", "level hand-over (2 barriers)", "A points + wave reduction", "window barrier + clear + barrier", "C corner reads / gradients / LDS adds",
              "barrier behind C", "D flush (global atomics)"]

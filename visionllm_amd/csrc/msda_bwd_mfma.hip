@@ -509,7 +509,8 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     f32x16_t acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    float *ap = st + hi * BT_RP + wave * 32 + l31;   // (this wave is the only reader of its 32 columns: it zeroes what it has read)
+                    asm volatile("" : "+v"(acc));   // (an accumulator in registers on every path: a constant-zero first product makes the skip paths re-materialise it)
+                    const unsigned ap_lds = (unsigned)(uintptr_t)(st3 + hi * BT_RP + wave * 32 + l31);   // (this wave is the only reader of its 32 columns: it zeroes what it has read)
                     if (!(BT_ABL & 32)) {
                         // only the k-steps whose queries have a corner in this chunk's pixel rows: group g of 8 slots (4 k-steps) touches the
                         // linear window pixels [(first row - y0) ww, (last row - y0 + 1) ww)
@@ -520,12 +521,21 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
 #pragma unroll
                         for (int g8 = 0; g8 < BT_NQ / 8; ++g8) {
                             if (gmask & (1u << g8)) {
-#pragma unroll
-                                for (int s2 = 4 * g8; s2 < 4 * g8 + 4; ++s2) {
-                                    const float sv = ap[2 * s2 * BT_RP];
-                                    ap[2 * s2 * BT_RP] = 0.f;
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, gor[s2], acc, 0, 0, 0);
-                                }
+                                // the group's four entries in flight together, zeroed behind the reads (LDS operations complete in order:
+                                // at most the four writes outstanding = the reads have landed); written out because the scheduler
+                                // otherwise serialises read -> wait -> MFMA through one register
+                                float sv0, sv1, sv2, sv3;
+                                asm volatile("ds_read_b32 %0, %4 offset:%6\n\tds_read_b32 %1, %4 offset:%7\n\tds_read_b32 %2, %4 offset:%8\n\t"
+                                             "ds_read_b32 %3, %4 offset:%9\n\tds_write_b32 %4, %5 offset:%6\n\tds_write_b32 %4, %5 offset:%7\n\t"
+                                             "ds_write_b32 %4, %5 offset:%8\n\tds_write_b32 %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(4)"
+                                             : "=&v"(sv0), "=&v"(sv1), "=&v"(sv2), "=&v"(sv3)
+                                             : "v"(ap_lds), "v"(0.f), "i"(2 * (4 * g8 + 0) * BT_RP * 4), "i"(2 * (4 * g8 + 1) * BT_RP * 4),
+                                               "i"(2 * (4 * g8 + 2) * BT_RP * 4), "i"(2 * (4 * g8 + 3) * BT_RP * 4)
+                                             : "memory");
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv0, gor[4 * g8 + 0], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv1, gor[4 * g8 + 1], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv2, gor[4 * g8 + 2], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv3, gor[4 * g8 + 3], acc, 0, 0, 0);
                             }
                         }
                     }
