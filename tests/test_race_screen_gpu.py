@@ -9,7 +9,8 @@ two-run identity check passes that 98 % of the time, a hundred launches do not. 
 
 The automatic choice is also compared against the two kernels with plain, compiler-visible reads that serve the same shape (generation 4
 and the gather kernel; 2e-6: only the association of the weighted sum differs), so a toolchain change that breaks generation 9's
-register assumptions shows as a difference (last item; generation 8 left the library in round 5).  Whole file: ~30 s on MI355X.
+register assumptions shows as a difference (last item; generation 8 left the library in round 5).  The backward the
+library chooses gets the same screen (40 launches per geometry).  Whole file: ~40 s on MI355X.
 """
 import math
 
@@ -79,6 +80,35 @@ def test_msda_cfg4_batch8_mixed_40_launches_identical():
         for i in range(40):
             out = _fwd(t)
             assert torch.equal(out, first), f"launch {i} differs"
+    finally:
+        _lib.set_option("msda_tiled", old)
+
+
+@pytest.mark.parametrize("name", sorted(PYRAMIDS))
+def test_msda_backward_40_launches_identical(name):
+    """The backward the library chooses (round 5: the matrix-core kernel was restructured -- per-level barriers removed, S^T zeroed by its
+    readers, the window copied by LDS-DMA behind the scatter): grad_sampling_loc / grad_attn_weight have one owner per element and
+    must repeat bit for bit; grad_value is accumulated with atomics (order varies: 2^-18 of the magnitude sum, the bound of
+    test_msda_gpu's backward tests); all three against the kernel without windows (msda_tiled = 0)."""
+    g = _mixed(PYRAMIDS[name], seed=len(PYRAMIDS[name]) + 1)
+    t = _dev(g)
+    torch.manual_seed(3)
+    go = torch.randn(t["loc"].shape[0], t["loc"].shape[1], t["value"].shape[2] * t["value"].shape[3], device=DEV)
+    bwd = lambda: A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64)
+    old = _lib.set_option("msda_tiled", 1)
+    try:
+        gv0, gl0, gw0 = bwd()
+        assert bool(torch.isfinite(gv0).all()) and bool(torch.isfinite(gl0).all()) and bool(torch.isfinite(gw0).all())
+        tol = 2.0 ** -18 * float(gv0.abs().max()) * 16 + 1e-7
+        for i in range(40):
+            gv, gl, gw = bwd()
+            assert torch.equal(gl, gl0) and torch.equal(gw, gw0), f"{name}: launch {i}: a per-point gradient differs from the first launch"
+            assert float((gv - gv0).abs().max()) <= tol, f"{name}: launch {i}: grad_value differs by {float((gv - gv0).abs().max()):.3g}"
+        _lib.set_option("msda_tiled", 0)
+        gv, gl, gw = bwd()
+        torch.testing.assert_close(gw, gw0, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gl, gl0, rtol=2e-3, atol=2e-3)
+        assert float((gv - gv0).abs().max()) <= 64 * tol
     finally:
         _lib.set_option("msda_tiled", old)
 
