@@ -632,7 +632,7 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
     // (msda_bwd_mfma.hip); VLLM_MSDA_BWD_LDS=1: the round-2 kernel that accumulates the window with LDS atomics (A/B)
     // (the matrix-core kernel addresses a (batch, head) slice with 32-bit byte offsets and stores grad_sampling_loc in 8-byte pieces)
     if ((long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv) &&
-        (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 && (long)S * M * D * 4 < (1L << 31)) {
+        (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 && (long)S * M * D * 4 < (1L << 31) && (long)B * M * Lq < (1L << 31)) {
         static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
         if (!lds_atomics)
             return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);

@@ -179,20 +179,25 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
 #endif
     const bool geo = uni(s_geo_ok) != 0;
     const int n_tiles = uni(geo ? s_tc[L] : (Lq + BT_TW - 1) / BT_TW);
-    const long n_items = (long)B * M * n_tiles;
-    const int xcd = blockIdx.x & 7;
-    const long ipx = (n_items + 7) >> 3;
-    const int blocks_per_xcd = gridDim.x >> 3;
+    const unsigned n_items = (unsigned)B * (unsigned)M * (unsigned)n_tiles;   // (< 2^31: the launchers' precondition B M Lq < 2^31)
+    const unsigned xcd = blockIdx.x & 7;
+    const unsigned ipx = (n_items + 7) >> 3;
+    const unsigned blocks_per_xcd = gridDim.x >> 3;
+    // (tile, (batch, head)) of this block's items: one 32-bit division pair here, then carried (the item index advances by a constant)
+    const unsigned step_t = blocks_per_xcd % (unsigned)n_tiles, step_bm = blocks_per_xcd / (unsigned)n_tiles;
+    unsigned t_u = (xcd * ipx + (blockIdx.x >> 3)) % (unsigned)n_tiles, bm_u = (xcd * ipx + (blockIdx.x >> 3)) / (unsigned)n_tiles;
 
     for (int i = tid; i < (BT_NQ * BT_RP + 3) / 4; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     int red_par = 0;
-    for (long j = blockIdx.x >> 3; j < ipx; j += blocks_per_xcd) {
-        const long item = (long)xcd * ipx + j;
+    for (unsigned j = blockIdx.x >> 3; j < ipx; j += blocks_per_xcd) {
+        const unsigned item = xcd * ipx + j;
         if (item >= n_items) break;
-        const int t = (int)(item % n_tiles);
-        const long bm = item / n_tiles;
-        const int m = (int)(bm % M);
-        const long b = bm / M;
+        const int t = (int)t_u;
+        const unsigned bm = bm_u;
+        t_u += step_t; bm_u += step_bm;
+        if (t_u >= (unsigned)n_tiles) { t_u -= (unsigned)n_tiles; ++bm_u; }
+        const int m = (int)(bm % (unsigned)M);
+        const long b = (long)(bm / (unsigned)M);
         int qH, qW, q0, ty, tx;
         if (DCN) {   // the query grid is the OUTPUT map
             qH = dq.Ho; qW = dq.Wo; q0 = 0;
@@ -607,7 +612,8 @@ int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_
 bool dcnv3_bwd_mfma_takes(const Dcnv3Geo &q)
 {
     return q.C == 32 && q.kh * q.kw >= 1 && q.kh * q.kw <= 4 * BT_MAXL && (long)q.N * q.H * q.W * q.G * q.C < (1L << 40) &&
-           (long)q.H * q.W * q.G * q.C * 4 < (1L << 31);   // (32-bit byte offsets inside an image)
+           (long)q.H * q.W * q.G * q.C * 4 < (1L << 31) &&   // (32-bit byte offsets inside an image)
+           (long)q.N * q.G * q.Ho * q.Wo < (1L << 31);        // (32-bit item index)
 }
 int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *mask, const float *grad_out, const Dcnv3Geo &q,
                           float offset_scale, float *grad_input, float *grad_offset, float *grad_mask, hipStream_t st)
