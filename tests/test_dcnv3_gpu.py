@@ -249,6 +249,49 @@ def test_backward_windowed_kernel_agrees_with_gather_kernel():
         assert float((a - b).abs().max()) <= 2e-5 * sc, (what, float((a - b).abs().max()), sc)
 
 
+@pytest.mark.parametrize("scale", [1.0, 1.7])
+def test_locations_on_and_next_to_integers_land_in_the_same_cell_in_every_kernel(scale):
+    """a location within an ulp of an integer must fall into the SAME cell in the gather backward, the windowed matrix-core
+    backward and the oracle (the reference's operation order: every product rounded on its own, `dcn_loc`): grad_offset is
+    discontinuous there, so one fused multiply-add in one kernel shows as an O(1) difference.  Offsets are constructed so that
+    p0 + (i d + offset) scale is an integer, or its fp32 neighbour above / below, for every point."""
+    from visionllm_amd import _lib
+    N, H, W, G, C, k = 1, 24, 40, 2, 32, 3
+    rng = np.random.default_rng(5)
+    inp = rng.standard_normal((N, H, W, G * C)).astype(np.float32)
+    msk = rng.random((N, H, W, G * k * k)).astype(np.float32)
+    go = rng.standard_normal((N, H, W, G * C)).astype(np.float32)
+    # target: an integer 0 .. 2 cells away from the undeformed point; offset = target / scale (then nudged by -1 / 0 / +1 ulp)
+    tgt = rng.integers(-2, 3, size=(N, H, W, G * k * k * 2)).astype(np.float32)
+    off = (tgt / np.float32(scale)).astype(np.float32)
+    nudge = rng.integers(-1, 2, size=off.shape)
+    off = np.where(nudge > 0, np.nextafter(off, np.float32(np.inf)), np.where(nudge < 0, np.nextafter(off, np.float32(-np.inf)), off)).astype(np.float32)
+    tt = lambda a: torch.from_numpy(a).to(DEV)
+    res = {}
+    old = _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", 0)
+    try:
+        for v in (0, 1):
+            _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", v)
+            res[v] = [g.cpu().numpy() for g in A.dcnv3_backward(tt(inp), tt(off), tt(msk), k, k, 1, 1, 1, 1, 1, 1, G, C, scale, tt(go))]
+    finally:
+        _lib.lib().vllm_set_option(b"dcnv3_bwd_tiled", old)
+    ri, ro, rm = O.backward(inp, off, msk, go, k, k, 1, 1, 1, 1, 1, 1, G, C, scale)
+    sc_o, sc_m = np.abs(ro).max(), np.abs(rm).max()
+    for v in (0, 1):
+        np.testing.assert_allclose(res[v][1], ro, rtol=2e-4, atol=1e-5 * sc_o, err_msg=f"grad_offset, dcnv3_bwd_tiled = {v}")
+        np.testing.assert_allclose(res[v][2], rm, rtol=2e-4, atol=1e-5 * sc_m, err_msg=f"grad_mask, dcnv3_bwd_tiled = {v}")
+    # and the forward kernels (continuous in the location, but a wrong cell at a map border drops or adds a corner)
+    ref = O.forward(inp, off, msk, k, k, 1, 1, 1, 1, 1, 1, G, C, scale)
+    old = _lib.set_option("dcnv3_tiled", 0)
+    try:
+        for mode in (0, 1, 3):
+            _lib.set_option("dcnv3_tiled", mode)
+            out = A.dcnv3_forward(tt(inp), tt(off), tt(msk), k, k, 1, 1, 1, 1, 1, 1, G, C, scale)
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5, err_msg=f"forward, dcnv3_tiled = {mode}")
+    finally:
+        _lib.set_option("dcnv3_tiled", old)
+
+
 def test_backward_argument_checks():
     x = torch.zeros(1, 4, 4, 8, device=DEV)
     off = torch.zeros(1, 4, 4, 2 * 9 * 2, device=DEV)
