@@ -26,7 +26,7 @@ find $O/prof_v $O/prof_i -type f -size +1M -delete
  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write -- python $R/bench.py --workload vitl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
 python tools/collect_pmc.py $O/fetch $O/write $O/pmc_traffic.json vitl | head -30   # copy to profiles/pmc_traffic.json: bench.py reads `traffic` from there
 find $O/fetch $O/write -name '*.csv' -size +2M -delete
-timeout 300 python tools/prof_msda9.py 2>&1 | grep -v amdgpu | tee $O/msda9_phases.txt   # (the MSDA backward kernels are unchanged this round: profiles/r04_msda_bwd_mfma_phases.txt)
+timeout 300 python tools/prof_msda9.py 2>&1 | grep -v amdgpu | tee $O/msda9_phases.txt   # (the MSDA backward: profiles/r05_msda_bwd_diet.txt, tools/msda_bwd_variants.{sh,py})
 # InternViT-6B traffic after the banded tile order (fc1 traffic <= 3x algorithmic)
 (cd /tmp; timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/fetch_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/write_i -- python $R/bench.py --workload internvit6b --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
