@@ -463,9 +463,10 @@ def extra_rooflines(dev, entry):
     f(); torch.cuda.synchronize()
     sec = event_time(f, 10)
     ab = 2.0 * feats.numel() * 2
-    out["splice"] = entry("-", f"splice_visual_tokens: torch.nonzero + vllm_scatter_rows_bf16 ({B * 5 * T} rows x {Cc} bf16 into [{B}, {Lt}, {Cc}])", "hbm", ab, sec, 0,
+    out["splice"] = entry("-", f"splice_visual_tokens = vllm_splice_visual_tokens_bf16: slot scan + row mover, checked ({B * 5 * T} rows x {Cc} bf16 into [{B}, {Lt}, {Cc}])", "hbm", ab, sec, 0,
                           HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
-                          note="not part of the step (SURVEY 8 row a12 / 8f row 4); time includes the index bookkeeping in torch (mask, nonzero, has_image gather); "
+                          note="not part of the step (SURVEY 8 row a12 / 8f row 4); one native call incl. the slot scan (one block) and the status read-back "
+                               "(the only host synchronisation; rounds 1-4: torch mask / nonzero / has_image gather + a scatter kernel: 225-236 us); "
                                "bytes = rows read + rows written")
     # the native row mover alone (the same rows, indices already on the device): what the kernel does without torch's mask / nonzero
     from visionllm_amd import _lib

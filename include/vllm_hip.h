@@ -362,6 +362,21 @@ int vllm_pixel_shuffle_bf16(const uint16_t *hidden, long tile_stride, int ld, in
 int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, uint16_t *dst, long n, int C, long dst_rows,
                            vllm_stream_t stream);
 
+/* The same splice with the index bookkeeping on the device (round 5): no host synchronisation, nothing copied twice.
+ *   input_ids [B, L] (device int64), image_features [n_tiles, T, C] bf16 in tile order, tiles_per_sample: HOST int32 [B] ('anyres'
+ *   list input; travels as a kernel argument) or NULL (one tile per sample), inputs_embeds [B, L, C] bf16, modified in place.
+ * Replaces modeling_visionllmv2.py:582-605: `selected = input_ids == imp_token_id`, `has_image = selected.sum(-1) != 0` (expanded to
+ * the tiles of a sample), `vit_embeds = image_features[has_image]`, `inputs_embeds[selected] = ... + vit_embeds`, and the rule of
+ * :597-603 when the counts differ: slots a whole multiple of the tokens -> the tokens repeat; any other mismatch is the reference's
+ * second failing assignment: NOTHING is written and status[2] = 1.
+ * workspace: device int32 [vllm_splice_workspace_ints(B, L, n_tiles)]; its first four words are {rows moved, visual tokens offered
+ * (tiles of samples with an image x T), error, <im_patch> slots}; status: device int32 [4] or NULL -> {slots, tokens offered, error,
+ * tiles kept}. */
+long vllm_splice_workspace_ints(int B, int L, int n_tiles);
+int vllm_splice_visual_tokens_bf16(const int64_t *input_ids, long imp_token_id, const uint16_t *image_features,
+                                   const int32_t *tiles_per_sample, int B, int L, int n_tiles, int T, int C,
+                                   uint16_t *inputs_embeds, int32_t *workspace, int32_t *status, vllm_stream_t stream);
+
 /* The per-sample token loops around the LLM (modeling_visionllmv2.py:440-527 [EMB] splice, :609-715 region features and
  * <region> slots, :775-787 [EMB] hidden states -> text_query) as index bookkeeping + ONE row mover:
  * dst[dst_idx[i], :] = src[src_idx[i], :] for i < n (device int64 indices; NULL = the identity; rows whose index falls

@@ -913,6 +913,49 @@ def test_visual_token_splice_matches_reference_semantics():
     ref[sel.reshape(-1)] = ref[sel.reshape(-1)] * 0.0 + feats[has_t].reshape(-1, C)
     out = splice_visual_tokens(emb.clone().to(DEV), ids.to(DEV), IMP, feats.to(DEV), split)
     assert torch.equal(out.cpu().reshape(B * L, C), ref)
+    # tensor `images` input: one tile per sample, no split sizes
+    ids1 = torch.randint(10, 50, (B, L))
+    ids1[0, 5:5 + T] = IMP
+    ids1[1, 0:T] = IMP
+    ids1[2, L - T:] = IMP
+    feats1 = bf(torch.randn(B, T, C))
+    ref1 = emb.clone().reshape(B * L, C)
+    ref1[(ids1 == IMP).reshape(-1)] = feats1.reshape(-1, C)
+    assert torch.equal(splice_visual_tokens(emb.clone().to(DEV), ids1.to(DEV), IMP, feats1.to(DEV)).cpu().reshape(B * L, C), ref1)
+    # :597-603: twice as many slots as tokens -> the tokens repeat
+    ids2 = torch.randint(10, 50, (1, L))
+    ids2[0, 2:2 + 2 * T] = IMP
+    feats2 = bf(torch.randn(1, T, C))
+    ref2 = emb[:1].clone().reshape(L, C)
+    ref2[(ids2 == IMP).reshape(-1)] = feats2.reshape(-1, C).repeat(2, 1)
+    assert torch.equal(splice_visual_tokens(emb[:1].clone().to(DEV), ids2.to(DEV), IMP, feats2.to(DEV)).cpu().reshape(L, C), ref2)
+    # any other mismatch: the reference's second assignment fails; here: an error and NOTHING written
+    ids3 = ids2.clone()
+    ids3[0, 2 + 2 * T] = IMP            # 2 T + 1 slots for T tokens
+    e3 = emb[:1].clone().to(DEV)
+    with pytest.raises(RuntimeError, match="shape mismatch: 13 <im_patch> slots cannot take 6 visual tokens"):
+        splice_visual_tokens(e3, ids3.to(DEV), IMP, feats2.to(DEV))
+    assert torch.equal(e3.cpu(), emb[:1])
+    with pytest.raises(RuntimeError, match="shape mismatch"):   # split sizes that do not add up to the tiles
+        splice_visual_tokens(emb.clone().to(DEV), ids.to(DEV), IMP, feats.to(DEV), [2, 1, 2])
+    # no <im_patch> token at all, and an empty batch of tiles: nothing to do
+    e4 = emb.clone().to(DEV)
+    splice_visual_tokens(e4, torch.randint(10, 50, (B, L)).to(DEV), IMP, feats[:0].to(DEV), [0, 0, 0])
+    assert torch.equal(e4.cpu(), emb)
+    # the bench's shape: 8 samples x 5 tiles x 576 tokens into 8 x 4096 positions (chunks of the slot scan cross sample boundaries)
+    torch.manual_seed(4)
+    B5, L5, C5, T5 = 8, 4096, 128, 576
+    ids5 = torch.randint(10, 50, (B5, L5))
+    split5 = [5, 0, 3, 5, 1, 5, 2, 5]
+    for b_, nt in enumerate(split5):
+        st_ = 17 * b_ + 3
+        ids5[b_, st_:st_ + nt * T5] = IMP
+    emb5 = bf(torch.randn(B5, L5, C5))
+    feats5 = bf(torch.randn(sum(split5), T5, C5))
+    ref5 = emb5.clone().reshape(B5 * L5, C5)
+    ref5[(ids5 == IMP).reshape(-1)] = feats5.reshape(-1, C5)      # (every sample with tiles has its slots: has_image keeps all of them)
+    out5 = splice_visual_tokens(emb5.clone().to(DEV), ids5.to(DEV), IMP, feats5.to(DEV), split5, check=False)
+    assert torch.equal(out5.cpu().reshape(B5 * L5, C5), ref5)
 
 
 def test_cfg1_vitl14_336_full_depth_plus_bridge_vs_oracle():

@@ -131,6 +131,79 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint16_t *__restri
     }
 }
 
+// ---- visual-token splice with the index bookkeeping on the device (round 5; modeling_visionllmv2.py:582-605) ----------------------
+// The reference selects with boolean masks (`image_features[has_image]`, `inputs_embeds[selected] = ...`): two host synchronisations
+// and two full copies.  Here one block lists the <im_patch> slots in order (chunked count + block scan), marks the samples that have
+// an image, lists THEIR tiles, and decides the token-count rule of :597-603 (equal, or slots a whole multiple of the tokens: repeated;
+// anything else: nothing is written and the error flag is raised); a second kernel moves a row per wave.
+// Workspace (int32): [0] rows to move, [1] visual tokens offered, [2] error, [3] slots found, [4 ...) slot positions [B L],
+// then the kept tiles [n_tiles], then (B > 512 only) the tiles per sample [B].
+constexpr int SPL_THREADS = 1024, SPL_HDR = 4, SPL_MAXB = 4096, SPL_BYVAL = 512;
+struct SplTiles { int n[SPL_BYVAL]; };   // tiles per sample by value (a kernel argument: no host-to-device copy) for B <= 512
+
+__global__ __launch_bounds__(SPL_THREADS) void splice_index_kernel(const int64_t *__restrict__ ids, long imp_id, const SplTiles tv,
+                                                                   const int32_t *__restrict__ tiles_dev, int tiles_mode, int B, int L,
+                                                                   int n_tiles, int T, int32_t *__restrict__ ws,
+                                                                   int32_t *__restrict__ status)
+{
+    __shared__ int s_cnt[SPL_THREADS / 64], s_has[SPL_MAXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = SPL_THREADS / 64;
+    const long n = (long)B * L;
+    // a wave owns a contiguous segment, read 64 positions (512 contiguous bytes) at a time
+    const long per = ((n + NW - 1) / NW + 63) & ~63L, lo = wave * per, hi = lo + per < n ? lo + per : n;
+    for (int b = tid; b < B; b += SPL_THREADS) s_has[b] = 0;
+    __syncthreads();
+    int c = 0;
+    for (long i0 = lo; i0 < hi; i0 += 64) {
+        const long i = i0 + lane;
+        const bool sel = i < hi && ids[i] == imp_id;
+        if (sel) s_has[i / L] = 1;   // (benign race: every writer stores 1)
+        c += __popcll(__ballot(sel));
+    }
+    if (lane == 0) s_cnt[wave] = c;
+    __syncthreads();
+    int r = 0, n_sel = 0;
+    for (int w = 0; w < NW; ++w) { const int v = s_cnt[w]; r += w < wave ? v : 0; n_sel += v; }
+    int32_t *slots = ws + SPL_HDR, *kept = ws + SPL_HDR + n;
+    for (long i0 = lo; i0 < hi; i0 += 64) {   // second pass over the (cached) ids: ranks from the ballot
+        const long i = i0 + lane;
+        const bool sel = i < hi && ids[i] == imp_id;
+        const unsigned long long m = __ballot(sel);
+        if (sel) slots[r + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+        r += __popcll(m);
+    }
+    if (tid == 0) {
+        int k = 0, t0 = 0, bad = 0;
+        for (int b = 0; b < B; ++b) {   // the tiles of the samples that have an image, in order (:585-592)
+            const int nt = tiles_mode == 0 ? 1 : tiles_mode == 1 ? tv.n[b] : tiles_dev[b];
+            if (nt < 0 || t0 + nt > n_tiles) { bad = 1; break; }
+            if (s_has[b])
+                for (int j = 0; j < nt; ++j) kept[k++] = t0 + j;
+            t0 += nt;
+        }
+        if (t0 != n_tiles) bad = 1;
+        const long n_vit = (long)k * T;
+        if (!bad && n_sel != n_vit && !(n_vit > 0 && n_sel > n_vit && n_sel % n_vit == 0)) bad = 1;
+        ws[0] = bad ? 0 : n_sel; ws[1] = (int32_t)n_vit; ws[2] = bad; ws[3] = n_sel;
+        if (status) { status[0] = n_sel; status[1] = (int32_t)n_vit; status[2] = bad; status[3] = k; }
+    }
+}
+
+// row i of the slot list <- visual token i (mod the tokens offered) of the kept tiles; a wave per row
+__global__ __launch_bounds__(256) void splice_move_kernel(const uint16_t *__restrict__ feats, const int32_t *__restrict__ ws, long n,
+                                                          int T, int C, uint16_t *__restrict__ embeds)
+{
+    const int cch = C / 8, lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const int n_move = ws[0], n_vit = ws[1];
+    const int32_t *slots = ws + SPL_HDR, *kept = ws + SPL_HDR + n;
+    for (long r = wave; r < n_move; r += nwaves) {
+        const int j = (int)(r % n_vit), kt = j / T, tok = j - kt * T;
+        move_row(feats + ((long)kept[kt] * T + tok) * C, embeds + (long)slots[r] * C, cch, lane);
+    }
+}
+
 static inline unsigned grid_for(long n)
 {
     long b = (n + 255) / 256;
@@ -199,6 +272,40 @@ extern "C" int vllm_scatter_rows_bf16(const uint16_t *src, const int64_t *idx, u
     VLLM_LAUNCH(scatter_rows_kernel, dim3(grid_for(n * 64)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, C,
                 dst_rows);
     VLLM_CHECK_LAUNCH("scatter_rows_kernel");
+    return VLLM_OK;
+}
+
+extern "C" long vllm_splice_workspace_ints(int B, int L, int n_tiles) { return (long)SPL_HDR + (long)B * L + n_tiles + (B > SPL_BYVAL ? B : 0); }
+
+extern "C" int vllm_splice_visual_tokens_bf16(const int64_t *input_ids, long imp_token_id, const uint16_t *image_features,
+                                              const int32_t *tiles_per_sample, int B, int L, int n_tiles, int T, int C,
+                                              uint16_t *inputs_embeds, int32_t *workspace, int32_t *status, vllm_stream_t stream)
+{
+    VLLM_REQUIRE(B >= 0 && L >= 0 && n_tiles >= 0 && T >= 0 && C > 0 && C % 8 == 0, "splice_visual_tokens: bad sizes (C must be a positive multiple of 8)");
+    VLLM_REQUIRE(B <= SPL_MAXB && (long)B * L < (1L << 31) && (long)n_tiles * T < (1L << 31), "splice_visual_tokens: too many samples / positions / tokens for one call");
+    VLLM_REQUIRE(workspace, "splice_visual_tokens: null workspace");
+    VLLM_REQUIRE((long)B * L == 0 || (input_ids && inputs_embeds && aligned16(inputs_embeds)), "splice_visual_tokens: null or unaligned pointer");
+    VLLM_REQUIRE((long)n_tiles * T == 0 || (image_features && aligned16(image_features)), "splice_visual_tokens: null or unaligned image_features");
+    SplTiles tv;
+    int mode = 0;
+    const int32_t *tdev = nullptr;
+    if (tiles_per_sample && B <= SPL_BYVAL) {
+        mode = 1;
+        for (int b = 0; b < B; ++b) tv.n[b] = tiles_per_sample[b];
+    } else if (tiles_per_sample) {   // (more than 512 samples: through the workspace)
+        mode = 2;
+        int32_t *d = workspace + SPL_HDR + (long)B * L + n_tiles;
+        VLLM_REQUIRE(hipMemcpyAsync(d, tiles_per_sample, sizeof(int32_t) * B, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess,
+                     "splice_visual_tokens: copy of the tiles per sample failed");
+        tdev = d;
+    }
+    VLLM_LAUNCH(splice_index_kernel, dim3(1), dim3(SPL_THREADS), 0, (hipStream_t)stream, input_ids, imp_token_id, tv, tdev, mode, B, L,
+                n_tiles, T, workspace, status);
+    VLLM_CHECK_LAUNCH("splice_index_kernel");
+    if ((long)B * L == 0 || (long)n_tiles * T == 0) return VLLM_OK;
+    VLLM_LAUNCH(splice_move_kernel, dim3(grid_for((long)B * L * 64)), dim3(256), 0, (hipStream_t)stream, image_features, workspace,
+                (long)B * L, T, C, inputs_embeds);
+    VLLM_CHECK_LAUNCH("splice_move_kernel");
     return VLLM_OK;
 }
 

@@ -1,45 +1,52 @@
 """Visual-token splice: writes the projector output into the ``<im_patch>`` slots of the LLM input embeddings
-(VisionLLMv2/visionllmv2/model/modeling_visionllmv2.py:582-605).  The reference does it with a boolean-mask assignment
-``inputs_embeds[selected] = inputs_embeds[selected] * 0.0 + vit_embeds``; here the slot positions come from
-``torch.nonzero`` (index bookkeeping) and the row movement is one HIP scatter kernel, in place."""
+(VisionLLMv2/visionllmv2/model/modeling_visionllmv2.py:582-605).  The reference does it with boolean-mask indexing
+(``image_features[has_image]``, ``inputs_embeds[selected] = inputs_embeds[selected] * 0.0 + vit_embeds``: two host
+synchronisations, two full copies); here the whole splice -- slot list, ``has_image``, the tiles of the samples that have an image,
+the token-count rule, the row movement -- is ONE native call without a host synchronisation (``vllm_splice_visual_tokens_bf16``,
+round 5; rounds 1-4: ``torch.nonzero`` + a scatter kernel)."""
+import ctypes
+
 import torch
 
 from . import _lib
 
 
-def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features, split_sizes=None):
+def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features, split_sizes=None, check=True):
     """inputs_embeds [B, L, C] (bf16, CUDA, modified in place and returned), input_ids [B, L],
     image_features [n_tiles, T, C] in tile order, split_sizes: tiles per sample ('anyres' list input) or None.
 
     Mirrors the reference's handling of samples without an image (their tiles are dropped, :585-592) and of a
     token-count mismatch (:597-603): features are repeated when the slots are a whole multiple of them; any other mismatch
-    raises, as the reference's second assignment does."""
+    raises, as the reference's second assignment does (and nothing has been written).  ``check=False`` skips reading the status
+    word back (the only host synchronisation left; a mismatch then leaves ``inputs_embeds`` untouched silently -- for callers
+    that validated the prompt on the host, or capture the step in a graph)."""
     B, L, C = inputs_embeds.shape
     if not inputs_embeds.is_cuda or inputs_embeds.dtype != torch.bfloat16 or not inputs_embeds.is_contiguous():
         raise RuntimeError("splice_visual_tokens: inputs_embeds must be a contiguous bf16 CUDA tensor")
-    selected = input_ids == imp_token_id
-    has_image = selected.sum(-1) != 0
+    dev = inputs_embeds.device
+    ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+    if tuple(ids.shape) != (B, L):
+        raise RuntimeError(f"splice_visual_tokens: input_ids {tuple(ids.shape)} does not match inputs_embeds {(B, L, C)}")
+    feats = image_features.to(device=dev, dtype=torch.bfloat16)
+    if feats.dim() != 3 or feats.shape[-1] != C:
+        raise RuntimeError(f"splice_visual_tokens: image_features must be [n_tiles, T, {C}], got {tuple(feats.shape)}")
+    feats = feats.contiguous()
+    n_tiles, T = int(feats.shape[0]), int(feats.shape[1])
+    tps = None
     if split_sizes is not None:
-        has_image = torch.cat([has_image[i][None].repeat(int(split_sizes[i])) for i in range(B)], dim=0)
-    # (round 5: when every sample has an image -- the usual case -- the tiles are used where they lie: the boolean-mask indexing
-    #  of the reference, :585-592, is a full copy of the visual tokens, 189 MB at 40 tiles x 576 x 4096)
-    if bool(has_image.all()):
-        vit = image_features.reshape(-1, C).to(inputs_embeds.dtype).contiguous()
-    else:
-        vit = image_features[has_image].reshape(-1, C).to(inputs_embeds.dtype).contiguous()
-    idx = torch.nonzero(selected.reshape(-1), as_tuple=False).reshape(-1)
-    n_sel, n_vit = idx.numel(), vit.shape[0]
-    if n_sel != n_vit:
-        if n_vit > 0 and n_sel > n_vit and n_sel % n_vit == 0:
-            vit = vit.repeat(n_sel // n_vit, 1)
-        else:
+        if len(split_sizes) != B:
+            raise RuntimeError("splice_visual_tokens: one split size per sample required")
+        tps = (ctypes.c_int32 * B)(*[int(v) for v in split_sizes])   # host array: travels as a kernel argument
+    L_ = _lib.lib()
+    ws = torch.empty(int(L_.vllm_splice_workspace_ints(B, L, n_tiles)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L_.vllm_splice_visual_tokens_bf16(_lib.ptr(ids), int(imp_token_id), _lib.ptr(feats), tps, B, L, n_tiles, T, C,
+                                                     _lib.ptr(inputs_embeds), _lib.ptr(ws), None, _lib.current_stream(dev)),
+                   "vllm_splice_visual_tokens_bf16")
+    if check:
+        _, n_vit, bad, n_sel = (int(v) for v in ws[:4].cpu())
+        if bad:
             raise RuntimeError(f"splice_visual_tokens: shape mismatch: {n_sel} <im_patch> slots cannot take {n_vit} visual tokens")
-    n = idx.numel()
-    if n:
-        with torch.cuda.device(inputs_embeds.device):
-            _lib.check(_lib.lib().vllm_scatter_rows_bf16(_lib.ptr(vit), _lib.ptr(idx.contiguous()), _lib.ptr(inputs_embeds),
-                                                         n, C, B * L, _lib.current_stream(inputs_embeds.device)),
-                       "vllm_scatter_rows_bf16")
     return inputs_embeds
 
 
