@@ -15,11 +15,18 @@ namespace vllm {
 constexpr int NORM_THREADS = 256;
 constexpr int NORM_MAX_CHUNKS = 8;  // upper bound of 16-byte chunks cached per lane (template MAXCH picks 1/2/4/8)
 
+// sum over the wave, in every lane (a scalar register): four DPP steps inside the rows of 16 lanes (quad butterfly, half mirror, mirror),
+// lane 15 of rows 0 / 2 onto rows 1 / 3, lane 31 onto the upper half, lane 63 read out.  (Rounds 1-4: six dependent ds_bpermute round
+// trips per value.)  A fixed tree: deterministic.
+template <int CTRL, int ROWS> __device__ __forceinline__ float dpp_sum_step(float x)
+{
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = dpp_sum_step<0xb1, 0xf>(v); v = dpp_sum_step<0x4e, 0xf>(v); v = dpp_sum_step<0x141, 0xf>(v); v = dpp_sum_step<0x140, 0xf>(v);
+    v = dpp_sum_step<0x142, 0xa>(v); v = dpp_sum_step<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // WPR = waves per row (1, 2 or 4).  A 256-thread block handles 4 / WPR rows.
