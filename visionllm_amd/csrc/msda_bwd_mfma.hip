@@ -74,6 +74,9 @@ constexpr int BT_MAXL = 8;
 #ifndef BT_STAGE_C       // 1: a window of up to ~130 pixels is copied into LDS (LDS-DMA, behind the first round's scatter) and phase C reads its
 #define BT_STAGE_C 1     //    corners there, after the rounds (128 B / clock instead of the L1's 64); 0: phase C from global memory, before the barrier
 #endif
+#ifndef BT_PRIO           // wave priority while a wave feeds the matrix core and flushes (its block's other phases, and the other blocks', wait less
+#define BT_PRIO 2         // for the round to end): -2 %
+#endif
 #ifndef BT_CULL          // 1: the grad_value product skips the k-steps (groups of 8 query slots) that have no corner in the wave's 32 pixels
 #define BT_CULL 1
 #endif
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 BT_TICK(6)   // scatter + barrier
                 // (2) this wave's 32-pixel chunk x grad_out on the matrix cores, (3) atomics straight from the accumulator layout
                 const int p0 = base + wave * 32;
+                if (BT_PRIO) __builtin_amdgcn_s_setprio(BT_PRIO);
                 if (p0 < npix) {   // (wave-uniform)
                     f32x16_t acc;
 #pragma unroll
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                         }
                     }
                 }
+                if (BT_PRIO) __builtin_amdgcn_s_setprio(0);
                 BT_TICK(7)   // MFMA + flush
                 if (base + BT_R < npix) __syncthreads();   // another round: every wave has read (and zeroed) its columns before the next scatter
                 BT_TICK(11)
