@@ -33,7 +33,7 @@
 // Summation order differs from the reference's atomics (as every atomic scatter does); tests compare against the oracle with the
 // tolerance of the other backward kernels.  History and measurements: NOTES/r05.md section 8, profiles/r05_msda_bwd_diet.txt
 // (rounds 3-4: 8 x 16 tiles, 2 blocks per CU, window staged in LDS for phase C, per-level hand-over through LDS: 4.05 ms at
-// cfg 4 / B = 8; now 2.65 ms).
+// cfg 4 / B = 8; now 2.41 ms).
 #include "common.hpp"
 #include "kernels.hpp"
 #include "msda_sample.hpp"
