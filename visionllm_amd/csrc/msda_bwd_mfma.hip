@@ -316,19 +316,18 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 }
             }
             if (l + 1 < L) load_points(l + 1);
-            // ---- C: per (query, point): the four corner reads and the two per-point gradients.  Nothing here depends on the block's
-            // window: it runs before the window barrier, each wave at its own pace.  The per-point gradients only need the four dot
-            // products  d_i = <grad_out, corner i>  over the 32 channels:  grad_attw = sum_i w_i d_i,
-            // grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),  grad_y = H aw (hw (d3 - d1) + lw (d4 - d2)).  The 8 lanes of a query (4 channels
-            // each) walk its four points in four steps -- the lower quad in the order 0 1 2 3, the upper quad 2 3 0 1 -- and of a point
-            // they only need the byte offsets of its four corners (clamped into the map; DPP broadcasts from the lane that owns the
-            // point): 4 x 16 bytes from global memory / L1 (a tile's window is a few KiB and is read by 64 queries) and 12 packed
-            // multiply-adds per step.  (Rounds 3-5 staged the window in LDS for this: two more barriers and a wipe per level pass, and
-            // no faster -- profiles/r05_msda_bwd_diet.txt.)  The sums over the 8 lanes are a reduce-scatter: one exchange between the
-            // quads (row_half_mirror: step t of one quad meets step t + 2 of the other -- the SAME point -- so the lower quad ends up
-            // with points 0, 1 and the upper quad with 2, 3: no selects), then a butterfly inside the quad: 24 DPP adds per query and
-            // level instead of 48.  Lanes 0, 1 of either quad own exactly the points they hold the sums of, and finish with their own
-            // fractions, validity and weight: the four points of a query leave as one 16-byte and one 32-byte piece.
+            // ---- C: per (query, point): the four corner reads and the two per-point gradients; run AFTER the rounds of the level (below).
+            // The per-point gradients only need the four dot products  d_i = <grad_out, corner i>  over the 32 channels:
+            // grad_attw = sum_i w_i d_i,  grad_x = W aw (hh (d2 - d1) + lh (d4 - d3)),  grad_y = H aw (hw (d3 - d1) + lw (d4 - d2)).
+            // The 8 lanes of a query (4 channels each) walk its four points in four steps -- the lower quad in the order 0 1 2 3, the upper
+            // quad 2 3 0 1 -- and of a point they only need where its corners are (DPP broadcasts from the lane that owns the point):
+            // staged window (<= ~125 pixels, copied by LDS-DMA behind the first round's scatter): ONE LDS address, 4 x 16 bytes at
+            // 128 B / clock; otherwise four clamped byte offsets and 4 x 16 bytes from global memory / L1 (64 B / clock: the whole
+            // phase is L1-bandwidth bound then); 12 packed multiply-adds per step.  The sums over the 8 lanes are a reduce-scatter:
+            // one exchange between the quads (row_half_mirror: step t of one quad meets step t + 2 of the other -- the SAME point -- so
+            // the lower quad ends up with points 0, 1 and the upper quad with 2, 3: no selects), then a butterfly inside the quad: 24
+            // DPP adds per query and level instead of 48.  Lanes 0, 1 of either quad own exactly the points they hold the sums of, and
+            // finish with their own fractions, validity and weight: the four points of a query leave as one 16-byte and one 32-byte piece.
             auto phase_c = [&](auto staged_tag, int wy0, int wx0, int www) {
                 constexpr bool STG = decltype(staged_tag)::value;
                 const char *vb = reinterpret_cast<const char *>(value + lbase) + sub * 16;
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             red_par ^= 1;
             if (lane == 0) { red[wave][0] = r0; red[wave][1] = r1; red[wave][2] = r2; red[wave][3] = r3; }
             BT_TICK(2)   // A: points + window reduction inside the wave
-            __syncthreads();   // (also: the previous level pass's un-scatter stores are behind every wave before this one stages its window)
+            __syncthreads();   // (also: every wave is done with the previous level pass -- S^T is zero again, the staging buffer has been read)
             const int y0 = uni(min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])));
             const int y1 = -uni(min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
             const int x0w = uni(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])));
@@ -483,11 +482,11 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 break;
             }
             for (int base = 0; base < npix; base += BT_R) {
-                // (1) scatter: lane (query slot, sub) owns point sub & 3 of its slot's queries (both lanes sub and sub + 4 evaluated it in
-                // phase A) and two of its four corners -- the upper pair for sub < 4, the lower pair otherwise: every lane of the wave
-                // has work, 8 LDS float atomics per lane and round.  (An LDS float atomic instruction costs ~100 cycles of the wave's
-                // time whatever its lane count; ordered plain read-add-write turns of the four points were measured no faster.)
-                // Corners outside the map or the round are skipped (the un-scatter sends their zero to the row's pad column).
+                // (1) scatter: lane (query slot, sub) owns ITS point (kpt) of its slot's queries and two of the point's four corners -- the
+                // upper pair for sub < 4, the lower pair otherwise (the two quads own every (point, corner row) once): every lane of the
+                // wave has work, 2 LDS float atomics per lane, pass and round.  (An LDS float atomic instruction costs ~100 cycles of the
+                // wave's time whatever its lane count; ordered plain read-add-write turns of the four points were measured no faster.)
+                // Corners outside the map or the round are skipped.  First: the round's table of pixel byte offsets for the flush.
                 if (tid < BT_R) {
                     const int pix = base + tid;
                     int wy = (int)((float)pix * ww_rcp), wx = pix - wy * ww;
