@@ -338,9 +338,9 @@ def kernel_rooflines(dev, msda_in, n_tiles, cfg, bridge_dims, iters=10, workload
         f(); torch.cuda.synchronize()
         sec = event_time(f, 3)
         ab = 2 * msda_bytes(t)
-        out["msda_bwd"] = entry("-", "msda_bwd_mfma_kernel + zero fill of the gradients (fp32, D32, encoder shape Lq=S=37485, B=8; grad_value = S^T x grad_out on "
+        out["msda_bwd"] = entry("-", "msda_bwd_mfma_kernel + zero fill of grad_value (fp32, D32, encoder shape Lq=S=37485, B=8; grad_value = S^T x grad_out on "
                                 "v_mfma_f32_32x32x2_f32)", "hbm", ab, sec, 0, HBM_PEAK_GBS, "GB/s", 1e9, algorithmic_bytes=ab,
-                                note="not part of the step (training only); time includes the torch.zeros of the three gradients")
+                                note="not part of the step (training only); time includes the allocation of the three gradients and the zero fill of grad_value (the kernel writes every element of the two per-point gradients: no memset for them since round 5)")
         del go
     except Exception as e:   # measurement extra: never fail the bench line for it
         out["msda_bwd"] = {"error": repr(e)}

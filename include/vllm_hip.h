@@ -158,6 +158,11 @@ int vllm_msda_backward_f32(const float *value, const int64_t *shapes, const int6
                            const float *loc, const float *attw, const float *grad_out,
                            int B, int S, int M, int D, int L, int Lq, int P,
                            float *grad_value, float *grad_loc, float *grad_attw, vllm_stream_t stream);
+/* 1 when vllm_msda_backward_f32 with these arguments writes EVERY element of grad_loc and grad_attw itself (the matrix-core kernel of
+ * the encoder self-attention shape: the gradients of a rejected point are stored as zeros), so the caller may pass those two
+ * uninitialised -- 460 MB of memset less at BASELINE cfg 4, B = 8; grad_value must be zero-filled in every case.  0: zero-fill all three. */
+int vllm_msda_backward_f32_writes_point_grads(const float *value, const float *loc, const float *grad_out, const float *grad_value,
+                                              const float *grad_loc, int B, int S, int M, int D, int L, int Lq, int P);
 int vllm_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
                            const double *loc, const double *attw, const double *grad_out,
                            int B, int S, int M, int D, int L, int Lq, int P,

@@ -620,6 +620,22 @@ static int launch_bwd_vec(const float *value, const int64_t *shapes, const int64
     return VLLM_OK;
 }
 
+// the matrix-core backward (msda_bwd_mfma.hip) takes the call: encoder self-attention shape, aligned operands, a (batch, head) slice
+// addressed with 32-bit byte offsets, grad_sampling_loc stored in 8-byte pieces, a 32-bit item index
+static bool bwd_takes_mfma(const float *value, const float *loc, const float *grad_out, const float *gv, const float *gl, int B, int S, int M,
+                           int D, int L, int Lq, int P)
+{
+    return (long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv) &&
+           (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 && (long)S * M * D * 4 < (1L << 31) && (long)B * M * Lq < (1L << 31);
+}
+
+extern "C" int vllm_msda_backward_f32_writes_point_grads(const float *value, const float *loc, const float *grad_out, const float *grad_value,
+                                                         const float *grad_loc, int B, int S, int M, int D, int L, int Lq, int P)
+{
+    static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
+    return !lds_atomics && bwd_takes_mfma(value, loc, grad_out, grad_value, grad_loc, B, S, M, D, L, Lq, P) ? 1 : 0;
+}
+
 extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                                       const float *loc, const float *attw, const float *grad_out, int B, int S,
                                       int M, int D, int L, int Lq, int P, float *gv, float *gl, float *gw,
@@ -630,9 +646,7 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
                  "msda_backward_f32: null pointer");
     // encoder self-attention shape: grad_value per (query tile, level) window as S^T x grad_out on the matrix cores
     // (msda_bwd_mfma.hip); VLLM_MSDA_BWD_LDS=1: the round-2 kernel that accumulates the window with LDS atomics (A/B)
-    // (the matrix-core kernel addresses a (batch, head) slice with 32-bit byte offsets and stores grad_sampling_loc in 8-byte pieces)
-    if ((long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv) &&
-        (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 && (long)S * M * D * 4 < (1L << 31) && (long)B * M * Lq < (1L << 31)) {
+    if (bwd_takes_mfma(value, loc, grad_out, gv, gl, B, S, M, D, L, Lq, P)) {
         static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
         if (!lds_atomics)
             return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);

@@ -378,8 +378,9 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     const float lh = him[p] - (float)hl, lw = wim[p] - (float)wl, hh = 1.f - lh, hw = 1.f - lw, aw = awp[p];
                     const bool u0 = hl >= 0, u1 = hl + 1 <= H - 1, c0 = wl >= 0, c1 = wl + 1 <= W - 1;
                     const float d1 = (u0 && c0) ? kd[0] : 0.f, d2 = (u0 && c1) ? kd[1] : 0.f, d3 = (u1 && c0) ? kd[2] : 0.f, d4 = (u1 && c1) ? kd[3] : 0.f;
-                    // MSDA: rejected points keep the caller's zero fill; DCNv3 writes every slot
-                    if ((sub & 2) == 0 && (DCN ? (qok[p] && l * PT + kpt < DP) : pok) && !(BT_ABL & 16)) {
+                    // every slot of a real query is written (a rejected point: zeros), so the two per-point gradients need no zero fill by
+                    // the caller (vllm_msda_backward_f32_writes_point_grads); DCNv3: kh kw slots per query
+                    if ((sub & 2) == 0 && qok[p] && (!DCN || l * PT + kpt < DP) && !(BT_ABL & 16)) {
                         const long pi = DCN ? qidx[p] * DP + l * PT + kpt : (qidx[p] * L + l) * PT + kpt;
                         grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;
                         *reinterpret_cast<float2_t *>(grad_loc + 2 * pi) =

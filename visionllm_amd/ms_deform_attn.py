@@ -95,8 +95,15 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if value.dtype not in (torch.float32, torch.float64):
         raise RuntimeError(f"ms_deform_attn_backward: unsupported dtype {value.dtype}")
     gv = torch.zeros_like(value)
-    gl = torch.zeros_like(sampling_loc)
-    gw = torch.zeros_like(attn_weight)
+    # (the reference zero-fills all three, ms_deform_attn_cuda.cu:118-120; the kernel of the encoder shape writes every element of the two
+    #  per-point gradients itself: no memset for them)
+    gl = torch.empty_like(sampling_loc)
+    gw = torch.empty_like(attn_weight)
+    if not (value.dtype == torch.float32 and value.is_contiguous() and sampling_loc.is_contiguous() and attn_weight.is_contiguous() and
+            _lib.lib().vllm_msda_backward_f32_writes_point_grads(_lib.ptr(value), _lib.ptr(sampling_loc), _lib.ptr(grad_output), _lib.ptr(gv),
+                                                                 _lib.ptr(gl), B, S, M, D, L, Lq, P)):
+        gl.zero_()
+        gw.zero_()
     _backward_into(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, gv, gl, gw,
                    (B, S, M, D, L, Lq, P))
     return [gv, gl, gw]
