@@ -188,11 +188,9 @@ class MultiScaleDeformableAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attw = ctx.saved_tensors
-        gv = torch.zeros_like(value)
-        gl = torch.zeros_like(loc)
-        gw = torch.zeros_like(attw)
-        ms_deform_attn_backward_(value.contiguous(), shapes, lsi, loc.contiguous(), attw.contiguous(),
-                                 grad_output.to(value.dtype).contiguous(), gv, gl, gw, ctx.im2col_step)
+        # (the allocating form: zero-fills only what the kernel that runs does not write itself)
+        gv, gl, gw = ms_deform_attn_backward(value.contiguous(), shapes, lsi, loc.contiguous(), attw.contiguous(),
+                                             grad_output.to(value.dtype).contiguous(), ctx.im2col_step)
         dv, dl, dw = ctx.in_dtypes
         return gv.to(dv), None, None, gl.to(dl), gw.to(dw), None
 
