@@ -52,6 +52,26 @@ def test_ops_fail_loudly_without_gpu_tensors():
                                torch.zeros(1, 1, 2, 1, 2), 64)
 
 
+def test_host_side_queries_of_round_5_need_no_gpu():
+    """The two pure host queries added in round 5: the splice workspace size, and whether the MSDA backward writes every per-point
+    gradient itself (decided from sizes / alignment alone; no kernel runs)."""
+    import ctypes
+    from visionllm_amd import _lib
+    L = _lib.lib()
+    assert L.vllm_splice_workspace_ints(8, 4096, 40) == 4 + 8 * 4096 + 40
+    assert L.vllm_splice_workspace_ints(600, 16, 7) == 4 + 600 * 16 + 7 + 600          # > 512 samples: the tiles per sample travel through it
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # decoder cross-attention shape (Lq != S) and a tiny encoder shape (below the tiled kernels' size threshold): the caller zero-fills
+    assert L.vllm_msda_backward_f32_writes_point_grads(p, p, p, p, p, 2, 5000, 8, 32, 4, 900, 4) == 0
+    assert L.vllm_msda_backward_f32_writes_point_grads(p, p, p, p, p, 2, 64, 8, 32, 4, 64, 4) == 0
+    # the encoder self-attention shape of BASELINE cfg 4 on aligned buffers: the matrix-core kernel writes them all
+    ptr = ctypes.c_void_p(1 << 20)
+    assert L.vllm_msda_backward_f32_writes_point_grads(ptr, ptr, ptr, ptr, ptr, 8, 37485, 8, 32, 4, 37485, 4) == 1
+    odd = ctypes.c_void_p((1 << 20) + 4)                                              # grad_loc only 4-byte aligned: another kernel runs
+    assert L.vllm_msda_backward_f32_writes_point_grads(ptr, ptr, ptr, ptr, odd, 8, 37485, 8, 32, 4, 37485, 4) == 0
+
+
 def test_module_constructor_errors_mirror_reference():
     # mmcv/tests/test_ops/test_ms_deformable_attn.py:25-30
     from visionllm_amd.ms_deform_attn import MSDeformAttn, MultiScaleDeformableAttention
