@@ -224,31 +224,10 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
 
         long qidx[BT_NPASS];
         bool qok[BT_NPASS];
-        float4_t go[BT_NPASS];   // this lane's 4 channels of grad_output of its query slots
 #pragma unroll
-        for (int p = 0; p < BT_NPASS; ++p) {
-            qidx[p] = pair_of(p * BT_QPP + slot0, qok[p]);
-            go[p] = *reinterpret_cast<const float4_t *>(grad_out + qidx[p] * D + sub * 4);
-            if (!qok[p]) go[p] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        }
-        // B operand of the grad_value product: grad_out[query 2 s + hi][channel l31], s = 0 .. 63 (zero for slots outside the map);
-        // it stays in registers for all levels and rounds of the item
-        float gor[BT_NQ / 2];
-        // slot 2 s + hi = (row (2 s) / BT_TW, column (2 s) % BT_TW + hi) of the tile: ONE block-uniform base address (a scalar register
-        // pair) + a 32-bit byte offset per load = the lane's constant part + a scalar
-        const char *gor_base = reinterpret_cast<const char *>(grad_out + ((b * Lq + q0 + (long)(ty * BT_TH) * qW + tx * BT_TW) * M + m) * D);
-        const unsigned gor_lane = (unsigned)(hi * (int)MD + l31) * 4u;
-        auto load_gor = [&]() {
-#pragma unroll
-            for (int s2 = 0; s2 < BT_NQ / 2; ++s2) {
-                const int dy = (2 * s2) / BT_TW, dx = (2 * s2) % BT_TW;
-                const bool ok = ty * BT_TH + dy < qH && tx * BT_TW + dx + hi < qW;
-                const unsigned off = (unsigned)((dy * qW + dx) * (int)MD) * 4u + gor_lane;
-                const float v = *reinterpret_cast<const float *>(gor_base + (ok ? off : 0u));
-                gor[s2] = ok ? v : 0.f;
-            }
-        };
-        load_gor();
+        for (int p = 0; p < BT_NPASS; ++p) qidx[p] = pair_of(p * BT_QPP + slot0, qok[p]);
+        // (the first level's points are requested FIRST: phase A waits for them, and the loads retire in order -- behind the 34 loads of
+        //  grad_out below it waited for all of them)
         // this lane's point (kpt) of its query of pass p at level l: 8 + 4 bytes straight from global memory (the 4 points of a query
         // are one 32-byte / 16-byte piece; lanes sub and sub + 4 read the same words), requested one level ahead.
         // DCNv3: offset -> location in input pixels, the reference's arithmetic (dcnv3_im2col_cuda.cuh:300-334: p0 = centre of the
@@ -282,6 +261,31 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             }
         };
         load_points(0);
+        asm volatile("" ::: "memory");   // (keeps the order of the requests)
+        float4_t go[BT_NPASS];   // this lane's 4 channels of grad_output of its query slots
+#pragma unroll
+        for (int p = 0; p < BT_NPASS; ++p) {
+            go[p] = *reinterpret_cast<const float4_t *>(grad_out + qidx[p] * D + sub * 4);
+            if (!qok[p]) go[p] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        // B operand of the grad_value product: grad_out[query 2 s + hi][channel l31], s = 0 .. 63 (zero for slots outside the map);
+        // it stays in registers for all levels and rounds of the item
+        float gor[BT_NQ / 2];
+        // slot 2 s + hi = (row (2 s) / BT_TW, column (2 s) % BT_TW + hi) of the tile: ONE block-uniform base address (a scalar register
+        // pair) + a 32-bit byte offset per load = the lane's constant part + a scalar
+        const char *gor_base = reinterpret_cast<const char *>(grad_out + ((b * Lq + q0 + (long)(ty * BT_TH) * qW + tx * BT_TW) * M + m) * D);
+        const unsigned gor_lane = (unsigned)(hi * (int)MD + l31) * 4u;
+        auto load_gor = [&]() {
+#pragma unroll
+            for (int s2 = 0; s2 < BT_NQ / 2; ++s2) {
+                const int dy = (2 * s2) / BT_TW, dx = (2 * s2) % BT_TW;
+                const bool ok = ty * BT_TH + dy < qH && tx * BT_TW + dx + hi < qW;
+                const unsigned off = (unsigned)((dy * qW + dx) * (int)MD) * 4u + gor_lane;
+                const float v = *reinterpret_cast<const float *>(gor_base + (ok ? off : 0u));
+                gor[s2] = ok ? v : 0.f;
+            }
+        };
+        load_gor();
 
         BT_TICK(0)   // item set-up: decode, grad_output / first level's locations requested
         for (int l = 0; l < L; ++l) {
