@@ -592,10 +592,6 @@ extern "C" int vllm_msda_sample_index_f32(const int64_t *shapes, const float *lo
 }
 
 namespace vllm {
-bool msda_bwd_tiled_ok(int D, int L, int P, int Lq, int S, const void *value, const void *grad_out, const void *loc);   // msda_bwd_tiled.hip
-int msda_bwd_tiled_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
-                          hipStream_t st);
 int msda_bwd_mfma_launch(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw,
                          hipStream_t st);   // msda_bwd_mfma.hip
@@ -625,15 +621,15 @@ static int launch_bwd_vec(const float *value, const int64_t *shapes, const int64
 static bool bwd_takes_mfma(const float *value, const float *loc, const float *grad_out, const float *gv, const float *gl, int B, int S, int M,
                            int D, int L, int Lq, int P)
 {
-    return (long)B * Lq != 0 && msda_bwd_tiled_ok(D, L, P, Lq, S, value, grad_out, loc) && aligned16(gv) &&
-           (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 && (long)S * M * D * 4 < (1L << 31) && (long)B * M * Lq < (1L << 31);
+    return (long)B * Lq != 0 && msda_tiled_enabled() && D == 32 && P == 4 && L <= 8 /* BT_MAXL of msda_bwd_mfma.hip */ && Lq == S && Lq >= 4096 && aligned16(value) &&
+           aligned16(grad_out) && aligned16(loc) && aligned16(gv) && (reinterpret_cast<uintptr_t>(gl) & 7u) == 0 &&
+           (long)S * M * D * 4 < (1L << 31) && (long)B * M * Lq < (1L << 31);
 }
 
 extern "C" int vllm_msda_backward_f32_writes_point_grads(const float *value, const float *loc, const float *grad_out, const float *grad_value,
                                                          const float *grad_loc, int B, int S, int M, int D, int L, int Lq, int P)
 {
-    static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
-    return !lds_atomics && bwd_takes_mfma(value, loc, grad_out, grad_value, grad_loc, B, S, M, D, L, Lq, P) ? 1 : 0;
+    return bwd_takes_mfma(value, loc, grad_out, grad_value, grad_loc, B, S, M, D, L, Lq, P) ? 1 : 0;
 }
 
 extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -644,14 +640,10 @@ extern "C" int vllm_msda_backward_f32(const float *value, const int64_t *shapes,
     if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
     VLLM_REQUIRE((long)B * Lq == 0 || (value && shapes && lsi && loc && attw && grad_out && gv && gl && gw),
                  "msda_backward_f32: null pointer");
-    // encoder self-attention shape: grad_value per (query tile, level) window as S^T x grad_out on the matrix cores
-    // (msda_bwd_mfma.hip); VLLM_MSDA_BWD_LDS=1: the round-2 kernel that accumulates the window with LDS atomics (A/B)
-    if (bwd_takes_mfma(value, loc, grad_out, gv, gl, B, S, M, D, L, Lq, P)) {
-        static const int lds_atomics = [] { const char *e = getenv("VLLM_MSDA_BWD_LDS"); return e && e[0] == '1' ? 1 : 0; }();
-        if (!lds_atomics)
-            return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
-        return msda_bwd_tiled_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
-    }
+    // encoder self-attention shape: grad_value per (query tile, level) window as S^T x grad_out on the matrix cores (msda_bwd_mfma.hip;
+    // the round-2 kernel that accumulated the window with LDS atomics is tools/experiments/msda_bwd_tiled.hip since round 5)
+    if (bwd_takes_mfma(value, loc, grad_out, gv, gl, B, S, M, D, L, Lq, P))
+        return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
     if ((long)B * Lq != 0 && D % 4 == 0 && (P == 1 || P == 2 || P == 4 || P == 8) && aligned16(value) &&
         aligned16(grad_out) && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0) {
         const int lpg = D / 4;
