@@ -17,9 +17,50 @@ def _run(*extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1", *extra],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    # the driver's contract: stdout holds ONE line, it is the last one, it fits well inside the driver's 8 KB stdout tail (the
+    # round-5 line had grown to 26 KB and BENCH_r05.json's `parsed` was null) and it is STRICT JSON (no NaN / Infinity tokens)
+    # (gloo's own "[Gloo] Rank r is connected ..." chatter may precede it on stdout for world > 1)
+    lines = p.stdout.splitlines()
+    assert lines and lines[-1].startswith("{") and sum(ln.startswith("{") for ln in lines) == 1, p.stdout[-2000:]
+    assert len(lines[-1].encode()) < 6144, len(lines[-1])
+
+    def _no_const(tok):
+        raise AssertionError(f"non-strict JSON token {tok}")
+    return json.loads(lines[-1], parse_constant=_no_const)
+
+
+def test_final_line_budget_on_a_full_size_record():
+    """The compacting path on the LARGEST record the bench has produced (profiles/r05_bench_line.json: ViT-L + nested InternViT-6B,
+    19 + 20 roofline entries, 26 KB): the final line stays under 6 KB, keeps what the driver and the review read (value,
+    ms_per_step, config.workload, roofline, rooflines.{attn, msda, gemm...}.frac, cpu_baseline, internvit6b.*) and is strict JSON."""
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    full["rooflines"]["attn"]["frac"] = float("nan")          # a poisoned figure must not produce a NaN token
+    extra = full.pop("internvit6b")
+    head = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    out, err = io.StringIO(), io.StringIO()
+    detail = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    had = os.path.exists(detail)
+    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+        bench.emit(dict(full, internvit6b=extra), head, full, extra)
+    if not had and os.path.exists(detail):
+        os.remove(detail)
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0].encode()) < 6144, [len(x) for x in lines]
+    rec = json.loads(lines[0], parse_constant=lambda t: (_ for _ in ()).throw(AssertionError(t)))
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["config"]["workload"].startswith("vitl14")
+    assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert rec["rooflines"]["attn"]["frac"] is None and rec["rooflines"]["msda"]["frac"] > 0
+    assert set(rec["rooflines"]["gemm"]) == {"frac", "us_per_launch", "launches_per_step", "traffic"}
+    assert "dcnv3" not in rec["rooflines"] and "dcnv3" in rec["isolated_frac"]         # isolated 8(f) rows: fraction only
+    assert rec["cpu_baseline"]["cores"] >= 1 and len(rec["cpu_baseline"]["sample"]) <= 300
+    iv = rec["internvit6b"]
+    assert iv["value"] > 0 and iv["roofline"]["frac"] > 0 and iv["rooflines"]["attn"]["frac"] > 0
+    assert err.getvalue().startswith("bench detail: {")
 
 
 def test_bench_respawns_and_runs_two_ranks_on_cpu():
