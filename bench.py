@@ -496,6 +496,69 @@ def _median_time(fn, reps=3, warmup=1):
 
 ALL_CORES_BUDGET_S = 20.0   # per repetition of the all-cores leg; beyond it the figure is reported as null, with the time seen
 
+_ALL_CORES_CHILD = r"""
+import sys, time, torch
+from transformers import CLIPVisionConfig, CLIPVisionModel
+cfg, th_ref, th_all = eval(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+torch.manual_seed(0)
+with torch.no_grad():
+    model = CLIPVisionModel(CLIPVisionConfig(**cfg, attn_implementation="eager")).eval()
+    x = torch.randn(1, 3, 336, 336)
+    def med(th, warm):
+        torch.set_num_threads(th)
+        ts = []
+        for i in range(3 + warm):
+            t0 = time.perf_counter(); model(pixel_values=x); ts.append(time.perf_counter() - t0)
+            if i == 0 and warm:
+                print("W", th, ts[0], flush=True)
+        return sorted(ts[warm:])[1]
+    print("R", th_ref, med(th_ref, 1), flush=True)
+    print("R", th_all, med(th_all, 1), flush=True)
+"""
+
+
+def _all_cores_leg(th_ref, th_all):
+    """ONE 336^2 tile through the full-depth ViT-L at th_ref and at th_all threads, 1 warm-up + 3 repetitions each, median -- in a
+    child process, so that an oversubscribed all-cores repetition (73.7 s seen on a 256-thread host) can be abandoned at the budget
+    instead of being waited for.  Returns (all_cores dict or None, note or None)."""
+    import queue
+    import subprocess
+    import threading
+    p = subprocess.Popen([sys.executable, "-c", _ALL_CORES_CHILD, repr(VIT), str(th_ref), str(th_all)], stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, text=True)
+    q = queue.Queue()
+    threading.Thread(target=lambda: [q.put(ln.split()) for ln in p.stdout] + [q.put(None)], daemon=True).start()
+    got, t_ref, t_all = {}, None, None
+    deadline = time.perf_counter() + 90.0          # start-up (imports) + the th_ref leg
+    try:
+        while True:
+            ln = q.get(timeout=max(0.1, deadline - time.perf_counter()))
+            if ln is None:
+                break
+            got[(ln[0], int(ln[1]))] = float(ln[2])
+            if ln[0] == "R" and int(ln[1]) == th_ref:
+                t_ref = float(ln[2])
+                deadline = time.perf_counter() + ALL_CORES_BUDGET_S          # the all-cores warm-up must report within the budget
+            elif ln[0] == "W" and int(ln[1]) == th_all:
+                deadline = time.perf_counter() + 3 * ALL_CORES_BUDGET_S + 5
+            elif ln[0] == "R" and int(ln[1]) == th_all:
+                t_all = float(ln[2])
+    except queue.Empty:
+        pass
+    finally:
+        if p.poll() is None:
+            p.kill()             # (the exact child we started)
+        p.wait()
+    if t_all is not None and t_ref is not None:
+        return dict(value=1.0 / t_all, unit="tiles/sec (ViT-L only, one 336^2 tile, full depth)", cores=th_all,
+                    same_sample_at_value_cores=1.0 / t_ref,
+                    sample=f"1 warm-up + 3 repetitions, median: {t_all:.2f}s at {th_all} threads, {t_ref:.2f}s at {th_ref}"), None
+    seen = got.get(("W", th_all))
+    return None, (f"not measured: ONE 336^2 tile through ViT-L at torch.set_num_threads({th_all}) " +
+                  (f"took {seen:.1f}s for the warm-up repetition and the three timed ones did not finish in {3 * ALL_CORES_BUDGET_S + 5:.0f}s" if seen is not None
+                   else f"did not finish its warm-up repetition within the {ALL_CORES_BUDGET_S:.0f}s budget (73.7s seen on a 256-thread host of this pool)") +
+                  (f"; the same sample at {th_ref} threads: {t_ref:.2f}s (median of 3)" if t_ref is not None else ""))
+
 
 def cpu_baseline(ivit=False):
     """`value`: the reference CPU path at the thread count we measured fastest (32), 1 warm-up + 3 repetitions, median (BASELINE.md
@@ -512,29 +575,7 @@ def cpu_baseline(ivit=False):
         main_leg["all_cores_note"] = f"`value` already uses every host thread ({n_all})"
         return main_leg
     try:
-        from transformers import CLIPVisionConfig, CLIPVisionModel
-        torch.manual_seed(0)
-        with torch.no_grad():
-            model = CLIPVisionModel(CLIPVisionConfig(**VIT, attn_implementation="eager")).eval()
-            x = torch.randn(1, 3, 336, 336)
-            run = lambda: model(pixel_values=x)  # noqa: E731
-            torch.set_num_threads(main_leg["cores"])
-            t_ref = _median_time(run, reps=3, warmup=1)
-            torch.set_num_threads(n_all)
-            t0 = time.perf_counter()
-            run()                                        # the warm-up of the all-cores leg, timed as the guard
-            t_warm = time.perf_counter() - t0
-            if t_warm > ALL_CORES_BUDGET_S:
-                main_leg["all_cores"] = None
-                main_leg["all_cores_note"] = (f"not measured: the warm-up repetition of ONE 336^2 tile through ViT-L at torch.set_num_threads({n_all}) took "
-                                              f"{t_warm:.1f}s (> {ALL_CORES_BUDGET_S:.0f}s budget per repetition); the same sample at {main_leg['cores']} "
-                                              f"threads: {t_ref:.2f}s (median of 3)")
-            else:
-                t_all = _median_time(run, reps=3, warmup=0)
-                main_leg["all_cores"] = dict(value=1.0 / t_all, unit="tiles/sec (ViT-L only, one 336^2 tile, full depth)", cores=n_all,
-                                             same_sample_at_value_cores=1.0 / t_ref,
-                                             sample=f"1 warm-up + 3 repetitions, median: {t_all:.2f}s at {n_all} threads, {t_ref:.2f}s at {main_leg['cores']}")
-        torch.set_num_threads(main_leg["cores"])
+        main_leg["all_cores"], main_leg["all_cores_note"] = _all_cores_leg(main_leg["cores"], n_all)
     except Exception as e:   # never fail the bench line for the second leg
         main_leg["all_cores"] = None
         main_leg["all_cores_note"] = "error: " + repr(e)[:160]

@@ -52,9 +52,11 @@ int vllm_device_info(char *name, int cap);
  * (generation 7) are rejected since round 4: that kernel is tools/experiments/msda_tiled7.hip.  "gemm_variant": 0 auto, 1 128x128 kernel, 2 256x256 8-phase
  * kernel, 4 8-phase kernel on the 32x32x16 MFMA.  "gemm_direct_store": the 8-phase kernel's epilogue goes 0 through LDS
  * (row-contiguous 16-byte stores), 1 straight from the accumulator layout, 2 automatic (default; same results either way).
- * "attn_variant": bit0 software-pipelined K, bit1 deferred rescale, bit2 s_setprio around MFMA clusters, bit3 hoisted
- * transpose reads, bit4 do not trim padding keys / padding query waves, 32 automatic (default).  (Bit 6 selected round 3's
- * hand-placed schedule, exactly as fast: tools/experiments/attn2.hip since round 4; the bit is ignored.)
+ * "attn_variant": 32 automatic (default) = 2 | 64 with the class-token split.  bit1 deferred rescale, bit4 do not trim padding keys /
+ * padding query waves (and no class-token split), bit6 O leaves through LDS as whole rows, bit7 NO class-token split (S = 64 n + 1:
+ * token 0 as the initial softmax state of every query, and -- where the n^2 body rows leave a spare wave in their last block -- as
+ * that wave's only query row; round 6), bit10 token 0 out of the key tiling only.  Bits 0, 2, 3 selected rounds 2-5 schedules that
+ * never became the default (software-pipelined K, s_setprio, hoisted transpose reads); they are ignored since round 6.
  * "dcnv3_tiled": DCNv3 forward for fp32, group channels 16 / 32, <= 9 points: 1 (default) the pipelined LDS-tiled kernel
  * (dcnv3_pipe.hip), 3 the two-blocks-per-CU LDS-tiled kernel (dcnv3_tiled.hip), 0 the gather kernel (same results to fp32
  * rounding); 2 / 4 = 1 / 3 with the phase clock (vllm_debug_counters then reads IT).

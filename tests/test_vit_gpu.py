@@ -478,7 +478,7 @@ def attn_sched(request):
 
 
 @pytest.mark.parametrize("D", [64, 128])
-@pytest.mark.parametrize("S", [1, 5, 32, 33, 63, 64, 65, 96, 97, 128, 129, 577, 1025])
+@pytest.mark.parametrize("S", [1, 5, 32, 33, 63, 64, 65, 96, 97, 128, 129, 193, 257, 577, 1025])
 def test_attention_vs_oracle(D, S, attn_sched):
     torch.manual_seed(S * 3 + D)
     B, H = 2, 3
@@ -541,10 +541,12 @@ def test_attention_online_softmax_rescale_branch(D, attn_sched):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 18])   # plain, deferred rescale (the default's), software-pipelined K, no padding trim (round 4: the variant list is cut to what differs structurally; the bit combinations ran green through round 3)
-@pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130)])
+# 0 plain (no deferred rescale, stores from the accumulators), 2 deferred rescale, 18 no padding trim (no class-token split), 66 = what
+# "automatic" selects, 194 the same WITHOUT the class-token split (the round-5 tiling), 1090 class token out of the KEY tiling only
+@pytest.mark.parametrize("variant", [0, 2, 18, 66, 194, 1090])
+@pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 130), (64, 193), (128, 257), (128, 256), (64, 321)])
 def test_attention_schedule_variants(variant, D, S):
-    """Every runtime-selectable schedule (pipelined K, deferred rescale, setprio, hoisted asm tr-reads) is exact."""
+    """Every runtime-selectable schedule (deferred rescale, O through LDS, class-token split on / off / keys only) is exact."""
     torch.manual_seed(variant + S)
     B, H = 2, 2
     qkv = torch.randn(B, S, 3, H, D, device=DEV) * 0.7

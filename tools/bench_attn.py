@@ -29,10 +29,11 @@ def run(n, S, H, D, variants=(2,), rounds=7, reps=20):
 
 
 if __name__ == "__main__":
-    # 2: round-1/2 schedule (attn.hip); 64 | v << 7: schedule 2 (attn2.hip), v bit0 setprio, bit1 split exp, bit2 add row sums
-    NEW = (64, 192, 320, 448, 576)
+    # round 6: 66 = automatic (deferred rescale, O through LDS, class-token split); +128: no split; +1024: class token out of the key
+    # tiling only
+    NEW = (66, 194, 1090)
     if len(sys.argv) > 1:
         NEW = tuple(int(x) for x in sys.argv[1].split(","))
-    run(40, 577, 16, 64, variants=(2,) + NEW)
-    run(8, 1025, 25, 128, variants=(2,) + NEW)
-    run(40, 1025, 25, 128, variants=(2,) + NEW[:2])
+    run(40, 577, 16, 64, variants=NEW)
+    run(40, 1025, 25, 128, variants=NEW)
+    run(5, 1025, 25, 128, variants=NEW)

@@ -24,75 +24,15 @@
 
 namespace vllm {
 
-#ifndef ATT_EPI_DEFAULT     // 64: the automatic schedule stores O through LDS (round 5: ViT-L 82.0 -> 79.1 us, InternViT-6B 657 -> 628 us at 40 tiles,
-                            // bit-identical outputs, profiles/r05_attn_epilogue.txt); 0: straight from the accumulators (attn_variant 2)
-#define ATT_EPI_DEFAULT 64
-#endif
-
-// K/V staging.  The per-lane part of every source address (row-in-tile * token stride + swizzled 16-byte chunk) does not
-// change from tile to tile: it is computed ONCE (kv_lane_offsets) and each tile's LDS-DMA is then
-// (uniform tile base in SGPRs) + (that 32-bit lane offset) -> the saddr form of global_load_lds with a uniform LDS
-// destination.  Left per tile, the 64-bit row multiply / clamp / readfirstlane chain was ~12 VALU per tile on a kernel
-// whose VALU issue is the bound.  Only the last tile of a ragged S clamps rows (keys >= S re-read key S-1; masked later).
-template <int D, int WPB = 4> struct KvStage {   // WPB = waves per block sharing the staging work
-    static constexpr int CPR = D / 8;           // 16-byte chunks per row
-    static constexpr int RPI = 64 / CPR;        // rows per wave instruction (1 KiB)
-    static constexpr int NI = KVBLK / RPI / WPB;  // instructions per wave
-};
-
-template <int D, bool ISV, int WPB = 4>
-__device__ __forceinline__ void kv_lane_offsets(int ts, int wave, int lane, uint32_t (&vo)[KvStage<D, WPB>::NI])
-{
-    typedef KvStage<D, WPB> G;
-#pragma unroll
-    for (int s = 0; s < G::NI; ++s) {
-        const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
-        const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));
-        vo[s] = (uint32_t)(r * ts + c * 8) * 2u;
-    }
-}
-
-template <int D, bool ISV, bool RAGGED = true, int WPB = 4>
-__device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
-                                         int wave, int lane, const uint32_t (&vo)[KvStage<D, WPB>::NI])
-{
-    typedef KvStage<D, WPB> G;
-    uint32_t off[G::NI];
-#pragma unroll
-    for (int s = 0; s < G::NI; ++s) off[s] = vo[s];
-    if (RAGGED && k0 + KVBLK > S) {   // block-uniform: ragged last tile, rows past the last key re-read key S-1
-#pragma unroll
-        for (int s = 0; s < G::NI; ++s) {
-            const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
-            const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));   // the LDS image keeps row r's swizzle
-            const int rr = k0 + r < S ? r : S - 1 - k0;
-            off[s] = (uint32_t)(rr * ts + c * 8) * 2u;
-        }
-    }
-    // ONE load site per instruction: (uniform tile base) + (32-bit lane offset) selects the saddr form, uniform LDS address.
-    // The empty asm keeps the zero-extension of the offset from being hoisted out of the tile loop as a 64-bit register
-    // pair (which turns every DMA back into a 64-bit VALU add + vaddr form).
-    const char *tile = reinterpret_cast<const char *>(base + (long)k0 * ts);
-#pragma unroll
-    for (int s = 0; s < G::NI; ++s) asm volatile("" : "+v"(off[s]));
-#pragma unroll
-    for (int s = 0; s < G::NI; ++s)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + off[s]),
-                                         (__attribute__((address_space(3))) void *)(lds_tile + (wave * G::NI + s) * 1024), 16,
-                                         0, 0);
-}
-
-// VAR bit0: software-pipelined K (scores of tile t+1 next to the softmax of tile t); bit1: deferred rescale;
-// bit2: s_setprio(1) around the MFMA clusters; bit3: V transpose-reads issued as inline asm BEFORE the softmax (the
-// compiler treats the tr-read builtin as 'may alias the LDS-DMA in flight' and puts s_waitcnt vmcnt(0) in front of it,
-// which drains the next tile's prefetch in the middle of every iteration).
+// DEFER: the running-max rescale is skipped while the maximum grows by less than 2^6 (cdna guide: defer-max).
 // EPI: 0 = every lane stores its 8-byte pieces straight from the accumulator layout (16 bytes per row and instruction: 32 partial
-// lines per store); 1 (round 5, the review's item 3-i / guide T21's LDS form) = the block's O tile goes through the (by then idle)
-// K/V ring and leaves as WHOLE ROWS, 16 bytes per lane, 8 (d = 64) or 4 (d = 128) full rows per instruction.
-template <int D, int VAR, bool F16 = false, int EPI = 0>
-__global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void attn_fwd_kernel(const AttnArgs a)
+// lines per store); 1 (round 5, guide T21's LDS form) = the block's O tile goes through the (by then idle) K/V ring and leaves
+// as WHOLE ROWS, 16 bytes per lane, 8 (d = 64) or 4 (d = 128) full rows per instruction.
+// (Rounds 2-5 carried three more schedule bits -- software-pipelined K, s_setprio around the MFMA clusters, hoisted asm
+//  transpose reads; each measured as fast or slower on both shapes, none was the default: removed in round 6, history keeps them.)
+template <int D, bool DEFER, bool F16 = false, int EPI = 0>
+__global__ __launch_bounds__(ATT_THREADS, D == 64 ? 4 : 2) void attn_fwd_kernel(const AttnArgs a)
 {
-    constexpr bool PIPE = (VAR & 1) != 0, DEFER = (VAR & 2) != 0, PRIO = (VAR & 4) != 0, ASMTR = (VAR & 8) != 0;
     constexpr int KS = D / 16;            // k-steps of the QK^T product
     constexpr int DB = D / 32;            // 32-wide output blocks
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
@@ -108,17 +48,23 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     const int qt = sidx % a.nqt;
     if (bh >= a.B * a.H) return;
     const int b = bh / a.H, head = bh % a.H;
+    const int Sk = a.S - a.kx;            // keys of the tile loop: kx .. S-1
 
     const uint16_t *qb = a.q + (long)b * a.q_bs + (long)head * a.q_hs;
-    const uint16_t *kb_ = a.k + (long)b * a.k_bs + (long)head * a.k_hs;
-    const uint16_t *vb_ = a.v + (long)b * a.v_bs + (long)head * a.v_hs;
+    const uint16_t *k0_ = a.k + (long)b * a.k_bs + (long)head * a.k_hs;
+    const uint16_t *v0_ = a.v + (long)b * a.v_bs + (long)head * a.v_hs;
+    const uint16_t *kb_ = k0_ + (long)a.kx * a.k_ts;
+    const uint16_t *vb_ = v0_ + (long)a.kx * a.v_ts;
 
     uint32_t kvo[KvStage<D>::NI], vvo[KvStage<D>::NI];
     kv_lane_offsets<D, false>(a.k_ts, wave, lane, kvo);
     kv_lane_offsets<D, true>(a.v_ts, wave, lane, vvo);
 
     // ---- Q fragments (B operand): lane (q = l31, hh) holds Q[q][16*ks + 8*hh .. +7] ----
-    const int q_row = qt * QBLK + wave * 32 + l31;
+    // rows of this wave: body rows qx + 32 g + l31; group a.cls_wave (> 0: the spare wave of the last block) is the class row alone
+    const int grp = qt * 4 + wave;
+    const bool cls_grp = a.cls_wave > 0 && grp == a.cls_wave;
+    const int q_row = cls_grp ? (l31 == 0 ? 0 : a.S) : a.qx + grp * 32 + l31;
     const int q_ld = q_row < a.S ? q_row : a.S - 1;
     bf16x8_t qf[KS];
 #pragma unroll
@@ -126,14 +72,39 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         qf[ks] = *reinterpret_cast<const bf16x8_t *>(qb + (long)q_ld * a.q_ts + ks * 16 + hh * 8);
 
     f32x16_t o[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
     const float c2 = a.scale_log2e;
-    const int nkt = (a.S + KVBLK - 1) / KVBLK;
-    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    if (a.kx) {
+        // token 0 as the initial state: s0 = q . k0 (this lane's half of the channels, then the other half's), p0 = 1, O = v0
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4_t kk = *reinterpret_cast<const uint4_t *>(k0_ + ks * 16 + hh * 8);
+            const uint4_t qq = __builtin_bit_cast(uint4_t, qf[ks]);
+            acc = dot2_acc<F16>(qq.x, kk.x, acc);
+            acc = dot2_acc<F16>(qq.y, kk.y, acc);
+            acc = dot2_acc<F16>(qq.z, kk.z, acc);
+            acc = dot2_acc<F16>(qq.w, kk.w, acc);
+        }
+        m_run = halves_sum(acc) * c2;
+        l_run = hh == 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const uint2_t vv = *reinterpret_cast<const uint2_t *>(v0_ + d * 32 + 8 * rq + 4 * hh);
+                o[d][4 * rq] = cvt16<F16>(vv.x & 0xffffu);
+                o[d][4 * rq + 1] = cvt16<F16>(vv.x >> 16);
+                o[d][4 * rq + 2] = cvt16<F16>(vv.y & 0xffffu);
+                o[d][4 * rq + 3] = cvt16<F16>(vv.y >> 16);
+            }
+    } else {
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    }
+    const int nkt = (Sk + KVBLK - 1) / KVBLK;
 
     // Loop-invariant LDS offsets.  swz_k / swz_v only look at key bits that come from the lane (the block constants
     // 32*kb, 16*u, +8 do not reach them), so every fragment address is (tile base) + (one of these) + (an immediate):
@@ -150,10 +121,9 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         }
     }
     // S^T = K Q^T for one staged K tile: two 32-key blocks, KS chained MFMAs each
-    // NKB = 1: the last tile holds <= 32 live keys (S = 577 / 1025: the single CLS-offset key) -- second key block skipped
+    // NKB = 1: the last tile holds <= 32 live keys -- second key block skipped
     auto qk = [&](uint32_t ks_, f32x16_t (&st)[2], auto nkb_) {
         constexpr int NKB = decltype(nkb_)::value;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -164,7 +134,6 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
                 st[kb] = mfma16<F16>(kf, qf[ks], st[kb]);
             }
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // online softmax of one score tile (raw scores; scale*log2e folded into the exp2 argument) + O^T += V^T P^T.
@@ -174,30 +143,14 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         constexpr bool MASK = decltype(mask_)::value;   // false: the tile is known to be full (steady-state steps)
         constexpr int NKB = decltype(nkb_)::value;
         constexpr float THR = DEFER ? 6.0f : 0.0f;
-        constexpr int NHOIST = ASMTR ? 16 : 1;          // tr-reads hoisted above the softmax: steps (kb,u) x d blocks
-        s16x4_t hv[NHOIST];                              // D=64: all 16 reads of the tile; D=128: the kb=0 half
-        if constexpr (ASMTR) {
-            const uint32_t vbase = vs_;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                // i -> (step, d, lo/hi) in the order the PV loop consumes them
-                const int per_step = 2 * DB;
-                const int step = i / per_step, rem = i % per_step, d = rem >> 1, hi_ = rem & 1;
-                const int kb = step >> 1, u = step & 1;
-                const int key = kb * 32 + 16 * u + 4 * hh + (i16 >> 2) + 8 * hi_;
-                const int c = d * 4 + 2 * g1 + ((i16 & 3) >> 1);
-                const uint32_t addr = vbase + key * (D * 2) + ((c ^ swz_v<D>(key)) << 4) + ((i16 & 1) << 3);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hv[i]) : "v"(addr));
-            }
-        }
         float mx = -1.0e30f;
-        if (MASK && k0 + KVBLK > a.S) {   // tail tile: mask keys >= S (block-uniform branch)
+        if (MASK && k0 + KVBLK > Sk) {   // tail tile: mask keys >= Sk (block-uniform branch)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    st[kb][r] = key < a.S ? st[kb][r] : -1.0e30f;
+                    st[kb][r] = key < Sk ? st[kb][r] : -1.0e30f;
                 }
         }
 #pragma unroll
@@ -231,18 +184,6 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             }
         l_run += psum[0] + psum[1];
         // O^T += V^T P^T ; k-slots of step (kb,u): regs 8u..8u+7 <-> keys 32kb+16u+4hh+{0..3, 8..11}
-        if constexpr (ASMTR) {
-            // the hoisted reads have landed (cdna guide 5.7, form iii).  The registers are in/out operands of the wait so
-            // that no compiler-made copy of them (tuple assembly for the MFMA operand) can be placed above it.
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]),
-                           "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]),
-                           "+v"(hv[15])
-                         :
-                         : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -253,64 +194,26 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
                 // lane (key 4hh + i16/4 (+8 for v_hi), chunk 4d + 2g1 + (i16&3)/2) of block (kb, u): vofs[d] + immediates
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
-                    const int hidx = ((kb * 2 + u) * DB + d) * 2;   // position in the hoisted set (if it is in it)
-                    s16x4_t v_lo, v_hi;
-                    if (ASMTR && hidx + 1 < NHOIST) {
-                        v_lo = hv[hidx < NHOIST ? hidx : 0];
-                        v_hi = hv[hidx + 1 < NHOIST ? hidx + 1 : 0];
-                    } else {
-                        const int blk = (kb * 32 + 16 * u) * (D * 2);   // immediate; key2 = key1 + 8 shares the swizzle
-                        v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk));
-                        v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk + 8 * (D * 2)));
-                    }
+                    const int blk = (kb * 32 + 16 * u) * (D * 2);   // immediate; key2 = key1 + 8 shares the swizzle
+                    const s16x4_t v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk));
+                    const s16x4_t v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t *)(uintptr_t)(vs_ + vofs[d] + blk + 8 * (D * 2)));
                     const bf16x8_t vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
                     o[d] = mfma16<F16>(vf, pf, o[d]);
                 }
             }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    constexpr std::integral_constant<bool, true> CTRUE{};
     constexpr std::integral_constant<int, 2> FULL{};
     constexpr std::integral_constant<int, 1> HALF{};
-    if constexpr (PIPE) {
-        // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1].  K runs ONE tile ahead of V: iteration t computes the scores of
-        // tile t+1 (MFMA) next to the softmax of tile t (VALU) -- independent streams inside one wave.
-        auto kslot = [&](int t) { return smem + (t & 1) * 2 * TILE; };
-        auto vslot = [&](int t) { return smem + (t & 1) * 2 * TILE + TILE; };
-        auto kaddr = [&](int t) { return (uint32_t)((t & 1) * 2 * TILE); };   // LDS byte addresses (dynamic LDS starts at 0)
-        auto vaddr = [&](int t) { return (uint32_t)((t & 1) * 2 * TILE + TILE); };
-        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, kslot(0), wave, lane, kvo);
-        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, vslot(0), wave, lane, vvo);
-        if (nkt > 1) stage_kv<D, false>(kb_, a.k_ts, KVBLK, a.S, kslot(1), wave, lane, kvo);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        f32x16_t sA[2], sB[2];
-        qk(kaddr(0), sA, FULL);
-
-        auto iteration = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
-            // K_{t+1}, V_t (issued one iteration ago) have landed for every wave, and every wave is done reading the
-            // slots of K_t / V_{t-1} that are refilled below (t = 0: the prologue's K_0 reads)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 2 < nkt) stage_kv<D, false>(kb_, a.k_ts, (t + 2) * KVBLK, a.S, kslot(t), wave, lane, kvo);
-            if (t + 1 < nkt) stage_kv<D, true>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, vslot(t + 1), wave, lane, vvo);
-            if (t + 1 < nkt) qk(kaddr(t + 1), nxt, FULL);
-            softmax_pv(cur, vaddr(t), t * KVBLK, FULL, CTRUE);
-        };
-        for (int t = 0; t < nkt; t += 2) {
-            iteration(t, sA, sB);
-            if (t + 1 < nkt) iteration(t + 1, sB, sA);
-        }
-    } else {
-        // plain schedule: K_t and V_t staged together one tile ahead; QK -> softmax -> PV in sequence.  Waves whose 32
-        // query rows are all padding (S = 577: wave 3 of the last query block) only stage and synchronise.
-        const bool live_wave = a.no_trim || qt * QBLK + wave * 32 < a.S;
-        const bool short_tail = !a.no_trim && a.S - (nkt - 1) * KVBLK <= 32;
-        stage_kv<D, false>(kb_, a.k_ts, 0, a.S, smem, wave, lane, kvo);
-        stage_kv<D, true>(vb_, a.v_ts, 0, a.S, smem + TILE, wave, lane, vvo);
+    {
+        // K_t and V_t staged together one tile ahead; QK -> softmax -> PV in sequence.  Waves whose 32 query rows are all
+        // padding only stage and synchronise.
+        const bool live_wave = a.no_trim || cls_grp || a.qx + grp * 32 < a.S;
+        const bool short_tail = !a.no_trim && Sk - (nkt - 1) * KVBLK <= 32;
+        stage_kv<D, false>(kb_, a.k_ts, 0, Sk, smem, wave, lane, kvo);
+        stage_kv<D, true>(vb_, a.v_ts, 0, Sk, smem + TILE, wave, lane, vvo);
         // One tile: wait for it, start the next one's DMA, QK -> softmax -> PV.  STAGE 0/1: the ring slot is a compile-time
         // constant (LDS fragment addresses become register + immediate); -1: taken from t.  NEXT 0: nothing to stage,
         // 1: the next tile is a full one (no row clamp code), 2: it may be the ragged last tile.
@@ -322,8 +225,8 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             const uint32_t ks_ = (uint32_t)(slot * 2 * TILE);   // LDS byte address of the K slot (dynamic LDS starts at 0)
             if constexpr (NEXT != 0) {
                 char *nx = smem + (slot ^ 1) * 2 * TILE;
-                stage_kv<D, false, NEXT == 2>(kb_, a.k_ts, (t + 1) * KVBLK, a.S, nx, wave, lane, kvo);
-                stage_kv<D, true, NEXT == 2>(vb_, a.v_ts, (t + 1) * KVBLK, a.S, nx + TILE, wave, lane, vvo);
+                stage_kv<D, false, NEXT == 2>(kb_, a.k_ts, (t + 1) * KVBLK, Sk, nx, wave, lane, kvo);
+                stage_kv<D, true, NEXT == 2>(vb_, a.v_ts, (t + 1) * KVBLK, Sk, nx + TILE, wave, lane, vvo);
             }
             if (live_wave) {
                 f32x16_t st[2];
@@ -343,7 +246,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
             if (t + 1 < n_main) tile_step(t + 1, FULL, C1, C1);
         }
         if (nkt >= 2) tile_step(nkt - 2, FULL, CDYN, C2);
-        if (short_tail) tile_step(nkt - 1, HALF, CDYN, C0); else tile_step(nkt - 1, FULL, CDYN, C0);
+        if (nkt >= 1) { if (short_tail) tile_step(nkt - 1, HALF, CDYN, C0); else tile_step(nkt - 1, FULL, CDYN, C0); }
     }
 
     // ---- finalize: O / l ; lane holds d = 32*db + 8*(r>>2) + 4*hh + (r&3) of query l31 ----
@@ -374,7 +277,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
         for (int i = 0; i < 32 / RPI; ++i) {
             const int row = i * RPI + rr;
             const uint4_t v = *reinterpret_cast<const uint4_t *>(wbase + row * (D * 2) + ((cc ^ (row & (CPRO - 1))) << 4));
-            const int qr = qt * QBLK + wave * 32 + row;
+            const int qr = cls_grp ? (row == 0 ? 0 : a.S) : a.qx + grp * 32 + row;
             if (qr < a.S) *reinterpret_cast<uint4_t *>(a.out + (((long)b * a.S + qr) * a.H + head) * D + cc * 8) = v;
         }
     } else if (q_row < a.S) {
@@ -391,6 +294,11 @@ __global__ __launch_bounds__(ATT_THREADS, (D == 64 && !(VAR & 9)) ? 4 : 2) void 
     }
 }
 
+template <int D, bool DEFER, bool F16, int EPI>
+static void attn_launch_one(const AttnArgs &a, unsigned grid, hipStream_t st)
+{
+    VLLM_LAUNCH((attn_fwd_kernel<D, DEFER, F16, EPI>), dim3(grid), dim3(ATT_THREADS), 4 * (size_t)KVBLK * D * 2, st, a);
+}
 
 int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
 {
@@ -402,39 +310,35 @@ int attn_fwd_launch(AttnArgs a, int D, hipStream_t st)
                      a.q_ts % 8 == 0 && a.k_ts % 8 == 0 && a.v_ts % 8 == 0 && a.q_hs % 8 == 0 && a.k_hs % 8 == 0 &&
                      a.v_hs % 8 == 0 && a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0,
                  "attn: q/k/v must be 16-byte aligned with strides multiple of 8 elements");
-    a.nqt = (a.S + QBLK - 1) / QBLK;
-    a.row0 = 0;
-    const long groups = ((long)a.B * a.H + 7) / 8;
-    const dim3 grid((unsigned)(groups * 8 * a.nqt)), block(ATT_THREADS);
-    const size_t lds = 4 * (size_t)KVBLK * D * 2;
-    // attn_variant: 32 = automatic; bits 0-3 are attn_fwd_kernel's VAR, bit 4 switches the padding trim off.  (Schedule 2 -- the
-    // hand-placed instruction stream of round 3, exactly as fast -- is tools/experiments/attn2.hip since round 4.)
+    // attn_variant: 32 = automatic (deferred rescale, O through LDS, class-token split).  bit 1: deferred rescale; bit 4: no padding
+    // trim (and no split); bit 6: O through LDS; bit 7: NO class-token split; bit 10: class token out of the KEY tiling only (what
+    // automatic does anyway when the body rows leave no spare wave).  Bits 0, 2, 3 (rounds 2-5 schedules) are ignored.
     int var = attn_variant();
-    if (var & 32) var = 2 | ATT_EPI_DEFAULT;
+    if (var & 32) var = 2 | 64;
     a.no_trim = (var >> 4) & 1;
-    const bool epi_lds = (var >> 6) & 1;      // bit 6: O through LDS, whole-row stores (needs 16-byte aligned output rows)
-    var &= 15;
-    if (epi_lds && var == 2 && aligned16(a.out)) {
-        if (a.f16) {
-            if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, true, 1>), grid, block, lds, st, a);
-            else VLLM_LAUNCH((attn_fwd_kernel<128, 2, true, 1>), grid, block, lds, st, a);
-        } else {
-            if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, false, 1>), grid, block, lds, st, a);
-            else VLLM_LAUNCH((attn_fwd_kernel<128, 2, false, 1>), grid, block, lds, st, a);
-        }
-        VLLM_CHECK_LAUNCH("attn_fwd_kernel");
-        return VLLM_OK;
-    }
-#define LA(DD, V) VLLM_LAUNCH((attn_fwd_kernel<DD, V>), grid, block, lds, st, a)
-#define LV(DD) do { switch (var) { case 0: LA(DD, 0); break; case 2: LA(DD, 2); break; case 6: LA(DD, 6); break; \
-    case 8: LA(DD, 8); break; case 10: LA(DD, 10); break; case 14: LA(DD, 14); break; case 3: LA(DD, 3); break; \
-    default: LA(DD, 2); } } while (0)
-    if (a.f16) {   // IEEE half: the default schedule only
-        if (D == 64) VLLM_LAUNCH((attn_fwd_kernel<64, 2, true>), grid, block, lds, st, a);
-        else VLLM_LAUNCH((attn_fwd_kernel<128, 2, true>), grid, block, lds, st, a);
-    } else if (D == 64) LV(64); else LV(128);
-#undef LV
-#undef LA
+    const bool defer = (var >> 1) & 1;
+    const bool epi_lds = ((var >> 6) & 1) && aligned16(a.out);
+    // the class-token split (attn_common.hpp): S = 64 n + 1
+    const bool split = !((var >> 7) & 1) && !a.no_trim && a.S > 64 && (a.S - 1) % KVBLK == 0;
+    const bool spare_wave = ((a.S - 1) / 32) % 4 != 0;          // the body rows do not fill their last block
+    a.kx = split ? 1 : 0;
+    a.qx = split && spare_wave && !((var >> 10) & 1) ? 1 : 0;
+    const int rows = a.S - a.qx;
+    a.nqt = (rows + QBLK - 1) / QBLK;
+    a.row0 = 0;
+    a.cls_wave = a.qx ? rows / 32 : 0;
+    const long groups = ((long)a.B * a.H + 7) / 8;
+    const unsigned grid = (unsigned)(groups * 8 * a.nqt);
+#define LD(DD) do { \
+        if (a.f16) { \
+            if (epi_lds) attn_launch_one<DD, true, true, 1>(a, grid, st); \
+            else attn_launch_one<DD, true, true, 0>(a, grid, st); \
+        } else if (!defer) attn_launch_one<DD, false, false, 0>(a, grid, st); \
+        else if (epi_lds) attn_launch_one<DD, true, false, 1>(a, grid, st); \
+        else attn_launch_one<DD, true, false, 0>(a, grid, st); \
+    } while (0)
+    if (D == 64) LD(64); else LD(128);
+#undef LD
     VLLM_CHECK_LAUNCH("attn_fwd_kernel");
     return VLLM_OK;
 }

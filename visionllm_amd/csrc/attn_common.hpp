@@ -1,4 +1,5 @@
-// Shared by the attention kernels (attn.hip; tools/experiments/attn2.hip: the round-3 hand-placed schedule, same speed).
+// Shared by the attention kernels (attn.hip; tools/experiments/attn2.hip: the round-3 hand-placed schedule, same speed;
+// tools/experiments/attn64.hip: round 6's 64-rows-per-wave body, slower).
 #pragma once
 #include "common.hpp"
 #include "kernels.hpp"
@@ -66,4 +67,82 @@ __device__ __forceinline__ float dot2_ones(uint32_t w, float acc)
     }
 }
 
+// K/V staging.  The per-lane part of every source address (row-in-tile * token stride + swizzled 16-byte chunk) does not
+// change from tile to tile: it is computed ONCE (kv_lane_offsets) and each tile's LDS-DMA is then
+// (uniform tile base in SGPRs) + (that 32-bit lane offset) -> the saddr form of global_load_lds with a uniform LDS
+// destination.  Left per tile, the 64-bit row multiply / clamp / readfirstlane chain was ~12 VALU per tile on a kernel
+// whose VALU issue is the bound.  Only the last tile of a ragged S clamps rows (keys >= S re-read key S-1; masked later).
+template <int D, int WPB = 4> struct KvStage {   // WPB = waves per block sharing the staging work
+    static constexpr int CPR = D / 8;           // 16-byte chunks per row
+    static constexpr int RPI = 64 / CPR;        // rows per wave instruction (1 KiB)
+    static constexpr int NI = KVBLK / RPI / WPB;  // instructions per wave
+};
+
+template <int D, bool ISV, int WPB = 4>
+__device__ __forceinline__ void kv_lane_offsets(int ts, int wave, int lane, uint32_t (&vo)[KvStage<D, WPB>::NI])
+{
+    typedef KvStage<D, WPB> G;
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s) {
+        const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
+        const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));
+        vo[s] = (uint32_t)(r * ts + c * 8) * 2u;
+    }
+}
+
+template <int D, bool ISV, bool RAGGED = true, int WPB = 4>
+__device__ __forceinline__ void stage_kv(const uint16_t *__restrict__ base, int ts, int k0, int S, char *lds_tile,
+                                         int wave, int lane, const uint32_t (&vo)[KvStage<D, WPB>::NI])
+{
+    typedef KvStage<D, WPB> G;
+    uint32_t off[G::NI];
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s) off[s] = vo[s];
+    if (RAGGED && k0 + KVBLK > S) {   // block-uniform: ragged last tile, rows past the last key re-read key S-1
+#pragma unroll
+        for (int s = 0; s < G::NI; ++s) {
+            const int r = (wave * G::NI + s) * G::RPI + lane / G::CPR;
+            const int c = (lane % G::CPR) ^ (ISV ? swz_v<D>(r) : swz_k<D>(r));   // the LDS image keeps row r's swizzle
+            const int rr = k0 + r < S ? r : S - 1 - k0;
+            off[s] = (uint32_t)(rr * ts + c * 8) * 2u;
+        }
+    }
+    // ONE load site per instruction: (uniform tile base) + (32-bit lane offset) selects the saddr form, uniform LDS address.
+    // The empty asm keeps the zero-extension of the offset from being hoisted out of the tile loop as a 64-bit register
+    // pair (which turns every DMA back into a 64-bit VALU add + vaddr form).
+    const char *tile = reinterpret_cast<const char *>(base + (long)k0 * ts);
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s) asm volatile("" : "+v"(off[s]));
+#pragma unroll
+    for (int s = 0; s < G::NI; ++s)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + off[s]),
+                                         (__attribute__((address_space(3))) void *)(lds_tile + (wave * G::NI + s) * 1024), 16,
+                                         0, 0);
+}
+
+// ---- the CLS "+1" (round 6) ------------------------------------------------------------------------------------------------
+// A ViT tile is S = 1 + n^2 tokens (modeling_intern_vit.py:85-89 concatenates the class token in front): 577 = 9 * 64 + 1,
+// 1025 = 16 * 64 + 1.  Tiled as it stands, the single extra token costs a tenth key tile and a fifth / ninth query block per
+// (tile, head) -- ~15 % of the MFMA work at ViT-L.  When (S - 1) % 64 == 0 the launcher takes token 0 out of the tilings:
+//   * as a KEY it is the initial state of every query's online softmax (m = q.k0 * c, l = 1, O = v0: one dot product and D
+//     loads per lane) -- the tile loop then walks keys 1 .. S-1 in exact 64-key tiles;
+//   * as a QUERY it moves into the spare wave of the last query block where the body rows leave one (576 rows = 4.5 blocks of
+//     four waves: the MFMA path with one live row, at no cost in block slots).  Where they do not (1024 rows = 8 blocks exactly)
+//     it stays where it was -- row 0 of the ordinary query tiling, 9 blocks -- and only the KEY side is split.
+//   Measured in round 6 (profiles/r06_attn_cls_split.txt; 40 tiles): d 64 / S 577: 77.6-78.5 us against 80.8-83.6 for the plain
+//   tiling; d 128 / S 1025: keys only 641 us, plain 650, keys + a VALU block per pair for the class row 654-674 (the block's
+//   serial load loops hold a block slot for ~10 us each); 192-row blocks of six waves for the 576 body rows (3 blocks per pair
+//   exactly, but 12 instead of 16 resident waves per CU): 123 us.  The losing forms are not in the library
+//   (tools/experiments/attn64.hip keeps the VALU class row next to the 64-rows-per-wave body that used it).
+// Results differ from the plain tiling by summation order only (P is rounded to 16 bits before P V on both paths).
+template <bool F16> __device__ __forceinline__ float cvt16(uint32_t h)
+{
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+    else return __uint_as_float(h << 16);
+}
+template <bool F16> __device__ __forceinline__ float dot2_acc(uint32_t x, uint32_t y, float acc)
+{
+    if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, x), __builtin_bit_cast(f16x2_t, y), acc, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, x), __builtin_bit_cast(bf16x2v_t, y), acc, false);
+}
 }  // namespace vllm

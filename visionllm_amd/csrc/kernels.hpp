@@ -159,6 +159,8 @@ struct AttnArgs {
     int nq = 1;                 // schedule 2: consecutive query tiles one block processes (filled by the launcher)
     int stagger = 0, n_cu = 256;   // schedule 2: start skew between the blocks of a CU [cycles], CUs of the device (launcher)
     int row0;                   // first query row of this launch (filled by the launcher)
+    int kx = 0, qx = 0;         // round 6: leading tokens taken out of the key tiling (initial softmax state) / the query tiling
+    int cls_wave = 0;           // > 0: the 32-row group index that holds query row 0 alone (the spare wave of the last query block)
     int no_trim;                // 1: process padding keys / padding query waves like live ones (A/B switch; launcher)
     float scale_log2e;
     int f16 = 0;                // 1: q / k / v / out are IEEE half (flash_attention.py:39-41 accepts fp16 and bf16); fp32 softmax either way
