@@ -368,6 +368,46 @@ def test_backward_f32_vectorised_vs_oracle(D, M, P):
     assert np.abs(rv32 - rv).max() <= 1e-3 * (1 + np.abs(rv).max())   # (fp32 oracle vs fp64 oracle: sanity)
 
 
+@pytest.mark.parametrize("case", ["mfma_encoder_shape", "forced_fallback", "decoder_shape", "misaligned_grad_loc"])
+def test_backward_allocating_flavour_never_returns_uninitialised_gradients(case, monkeypatch):
+    """ms_deform_attn_backward allocates grad_sampling_loc / grad_attn_weight UNINITIALISED when
+    vllm_msda_backward_f32_writes_point_grads says the kernel will write every element, and zero-fills them otherwise.  The query and
+    the dispatch inside vllm_msda_backward_f32 must agree: here torch.empty_like hands out NaN-poisoned buffers and the result must be
+    finite and EQUAL to the in-place flavour run on zero-filled buffers -- on the matrix-core path (encoder shape), with the LDS-tiled
+    kernels switched off, with Lq != S, and with a grad_sampling_loc the vector path must refuse (the query sees the caller's pointer)."""
+    from visionllm_amd import _lib
+    shapes = [(40, 36), (20, 18), (10, 9), (5, 5)]
+    Lq = None if case != "decoder_shape" else 300
+    g = make_inputs(2, 8, 32, shapes, 4, Lq=Lq, mode="stress", seed=11)
+    t = {k: _t(v) for k, v in g.items()}
+    go = torch.randn(t["loc"].shape[0], t["loc"].shape[1], 8 * 32, device=DEV)
+    real_empty_like = torch.empty_like
+
+    def poisoned(x, *a, **k):
+        r = real_empty_like(x, *a, **k)
+        if r.is_floating_point():
+            r.fill_(float("nan"))
+        if case == "misaligned_grad_loc" and r.shape == t["loc"].shape:
+            big = torch.full((x.numel() + 1,), float("nan"), dtype=x.dtype, device=x.device)
+            r = big[1:].view(x.shape)          # 4 bytes off a 16-byte boundary
+        return r
+    old = _lib.set_option("msda_tiled", 0) if case == "forced_fallback" else None
+    try:
+        monkeypatch.setattr(A.torch, "empty_like", poisoned)
+        gv, gl, gw = A.ms_deform_attn_backward(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, 64)
+        monkeypatch.setattr(A.torch, "empty_like", real_empty_like)
+        rv, rl, rw = torch.zeros_like(t["value"]), torch.zeros_like(t["loc"]), torch.zeros_like(t["attw"])
+        A.ms_deform_attn_backward_(t["value"], t["shapes"], t["lsi"], t["loc"], t["attw"], go, rv, rl, rw, 64)
+    finally:
+        if old is not None:
+            _lib.set_option("msda_tiled", old)
+    assert torch.isfinite(gl).all() and torch.isfinite(gw).all() and torch.isfinite(gv).all()
+    # (grad_value is accumulated with atomics: order-dependent in the last bits; the per-point gradients are written once)
+    torch.testing.assert_close(gl, rl, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gw, rw, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gv, rv, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("spread", ["near", "medium", "far"])
 @pytest.mark.parametrize("shapes,B,M", [([(72, 64), (36, 32), (18, 16), (9, 8)], 2, 8), ([(65, 67), (33, 34)], 1, 3)])
 def test_backward_f32_encoder_shape_tiled_vs_plain_vs_oracle(shapes, B, M, spread):

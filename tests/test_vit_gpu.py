@@ -958,6 +958,16 @@ def test_visual_token_splice_matches_reference_semantics():
     ref5[(ids5 == IMP).reshape(-1)] = feats5.reshape(-1, C5)      # (every sample with tiles has its slots: has_image keeps all of them)
     out5 = splice_visual_tokens(emb5.clone().to(DEV), ids5.to(DEV), IMP, feats5.to(DEV), split5, check=False)
     assert torch.equal(out5.cpu().reshape(B5 * L5, C5), ref5)
+    #  check=False + return_status: the mismatch is visible LATER without a synchronisation at the call
+    from visionllm_amd.splice import splice_status_ok
+    out6, st6 = splice_visual_tokens(emb5.clone().to(DEV), ids5.to(DEV), IMP, feats5.to(DEV), split5, check=False, return_status=True)
+    assert st6.is_cuda and splice_status_ok(st6) and torch.equal(out6.cpu().reshape(B5 * L5, C5), ref5)
+    bad_ids = ids5.clone()
+    bad_ids[0, 0] = IMP                                             # one slot too many: nothing may be written
+    out7, st7 = splice_visual_tokens(emb5.clone().to(DEV), bad_ids.to(DEV), IMP, feats5.to(DEV), split5, check=False, return_status=True)
+    assert torch.equal(out7.cpu(), emb5)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        splice_status_ok(st7)
 
 
 def test_cfg1_vitl14_336_full_depth_plus_bridge_vs_oracle():

@@ -343,6 +343,10 @@ extern "C" int vllm_dcnv3_backward_f16(const uint16_t *input, const uint16_t *of
     VLLM_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "dcnv3_backward_f16: null pointer");
     const long need = vllm_dcnv3_backward_f16_workspace(N, H, W, G, C, kh, kw, sh, sw, ph, pw, dh, dw);
     VLLM_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), "dcnv3_backward_f16: workspace of %ld bytes (16-byte aligned) required", need);
+    //  the conversion passes move 8 halves = 16 bytes per lane on the caller's pointers
+    VLLM_REQUIRE(aligned16(input) && aligned16(offset) && aligned16(mask) && aligned16(grad_output) && aligned16(grad_input) &&
+                     aligned16(grad_offset) && aligned16(grad_mask),
+                 "dcnv3_backward_f16: tensors must be 16-byte aligned (a view with a storage offset that is not a multiple of 8 halves: make it contiguous first)");
     const long n_in = (long)N * H * W * G * C, n_out = (long)N * q.Ho * q.Wo * G * C, n_msk = (long)N * q.Ho * q.Wo * G * kh * kw;
     hipStream_t st = (hipStream_t)stream;
     float *w = static_cast<float *>(workspace);

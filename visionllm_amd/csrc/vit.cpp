@@ -148,8 +148,18 @@ extern "C" int vllm_vit_forward(const VllmVitDesc *d, const void *pixels, int n,
                             gemm_ln(d->act, hmid, C, L0.fc1_w_ln, C, nullptr, mid, I, I, C, nullptr, nullptr, 0, nullptr, ln_b, nullptr, L0.fc1_bias_ln) == VLLM_OK &&
                             gemm_ln(EPI_RESIDUAL, mid, I, L0.fc2_w, I, L0.fc2_b, hmid, C, C, I, L0.ls2, hmid, C, ln_a, nullptr, nullptr, nullptr) == VLLM_OK;
             dry = 0;
+            //  the dry run sees layer 0's operands and the workspace buffers; the real launches use state(i) -- which may be
+            // caller-provided hidden_states buffers -- and every layer's own vectors.  The wide fold has no tile-wise fall-back, so a
+            // single operand the persistent schedule would refuse (16-byte alignment) switches the fold off for the whole pass.
+            bool aligned = true;
+            for (int i = 0; i <= d->num_layers && aligned; ++i) aligned = aligned16(state(i));
+            for (int i = 0; i < d->num_layers && aligned; ++i) {
+                const VllmVitLayer &Li = d->layers[i];
+                const void *ops[] = {Li.qkv_w_ln, Li.fc1_w_ln, Li.proj_w, Li.fc2_w, Li.proj_b, Li.fc2_b, Li.ls1, Li.ls2, Li.qkv_bias_ln, Li.fc1_bias_ln};
+                for (const void *q : ops) aligned = aligned && (!q || aligned16(q));
+            }
             if (getenv("VLLM_VIT_DEBUG")) fprintf(stderr, "vit: wide norm fold dry run at M=%ld C=%d I=%d: %s (%s)\n", (long)M, C, I, ok ? "taken" : "refused", vllm_last_error());
-            if (!ok) shapes_fold = false;
+            if (!ok || !aligned) shapes_fold = false;
         } else shapes_fold = false;
         if (shapes_fold && hipMemsetAsync(ln_a, 0, (size_t)2 * M * 16 * sizeof(float), st) != hipSuccess) {   // (the wide layout's unused slots are read as zeros)
             set_error("vit: hipMemsetAsync of the folded-norm statistics failed");

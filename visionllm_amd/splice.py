@@ -2,8 +2,11 @@
 (VisionLLMv2/visionllmv2/model/modeling_visionllmv2.py:582-605).  The reference does it with boolean-mask indexing
 (``image_features[has_image]``, ``inputs_embeds[selected] = inputs_embeds[selected] * 0.0 + vit_embeds``: two host
 synchronisations, two full copies); here the whole splice -- slot list, ``has_image``, the tiles of the samples that have an image,
-the token-count rule, the row movement -- is ONE native call without a host synchronisation (``vllm_splice_visual_tokens_bf16``,
-round 5; rounds 1-4: ``torch.nonzero`` + a scatter kernel)."""
+the token-count rule, the row movement -- is ONE native call (``vllm_splice_visual_tokens_bf16``, round 5; rounds 1-4:
+``torch.nonzero`` + a scatter kernel).  The call itself does not synchronise; with ``check=True`` (the default, and what bench.py
+times) the wrapper then reads the 4-int status word back, which IS a host synchronisation -- the one the reference's error
+behaviour costs.  ``check=False`` skips it and hands the status tensor to the caller instead (``status=`` / ``return_status``).
+Limit: B <= 4096 samples per call (the slot scan is one block; the torch implementation of rounds 1-4 had none)."""
 import ctypes
 
 import torch
@@ -11,15 +14,17 @@ import torch
 from . import _lib
 
 
-def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features, split_sizes=None, check=True):
+def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features, split_sizes=None, check=True, return_status=False):
     """inputs_embeds [B, L, C] (bf16, CUDA, modified in place and returned), input_ids [B, L],
     image_features [n_tiles, T, C] in tile order, split_sizes: tiles per sample ('anyres' list input) or None.
 
     Mirrors the reference's handling of samples without an image (their tiles are dropped, :585-592) and of a
     token-count mismatch (:597-603): features are repeated when the slots are a whole multiple of them; any other mismatch
     raises, as the reference's second assignment does (and nothing has been written).  ``check=False`` skips reading the status
-    word back (the only host synchronisation left; a mismatch then leaves ``inputs_embeds`` untouched silently -- for callers
-    that validated the prompt on the host, or capture the step in a graph)."""
+    word back (the only host synchronisation left) -- for callers that validated the prompt on the host, or capture the step in a
+    graph; a mismatch then leaves ``inputs_embeds`` untouched, and ``return_status=True`` returns ``(inputs_embeds, status)`` with
+    ``status`` the DEVICE int32 tensor ``[_, n_visual_tokens, mismatch, n_slots]`` so that it can be checked later
+    (``splice_status_ok(status)``) without a synchronisation now."""
     B, L, C = inputs_embeds.shape
     if not inputs_embeds.is_cuda or inputs_embeds.dtype != torch.bfloat16 or not inputs_embeds.is_contiguous():
         raise RuntimeError("splice_visual_tokens: inputs_embeds must be a contiguous bf16 CUDA tensor")
@@ -47,7 +52,18 @@ def splice_visual_tokens(inputs_embeds, input_ids, imp_token_id, image_features,
         _, n_vit, bad, n_sel = (int(v) for v in ws[:4].cpu())
         if bad:
             raise RuntimeError(f"splice_visual_tokens: shape mismatch: {n_sel} <im_patch> slots cannot take {n_vit} visual tokens")
+    if return_status:
+        return inputs_embeds, ws[:4]
     return inputs_embeds
+
+
+def splice_status_ok(status):
+    """Deferred form of splice_visual_tokens' check: reads a status tensor returned with ``return_status=True`` (synchronises) and
+    raises the reference's shape-mismatch error if that splice wrote nothing."""
+    _, n_vit, bad, n_sel = (int(v) for v in status.cpu())
+    if bad:
+        raise RuntimeError(f"splice_visual_tokens: shape mismatch: {n_sel} <im_patch> slots cannot take {n_vit} visual tokens")
+    return True
 
 
 # ---- the other per-sample token loops around the LLM (SURVEY.md section 8, row f4): index bookkeeping in torch, row movement
