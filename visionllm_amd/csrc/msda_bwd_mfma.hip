@@ -39,56 +39,28 @@
 #include "msda_sample.hpp"
 #include "dcnv3_geo.hpp"
 
-// Timing-only ablation builds: -DBT_ABL=<mask>.  1: no flush atomics, 2: no sparse-path atomics, 4: no S scatter,
-// 8: no value corner reads, 16: no grad_loc / grad_attw stores (phase C becomes dead code), 32: no MFMA, 64: no grad_value rounds at
-// all, 128: the flush as plain stores, 256: every second flush atomic, 512: all of them inside 1 MiB, 1024: product computed, nothing
-// flushed.
-#ifndef BT_ABL
-#define BT_ABL 0
-#endif
-
-#ifdef BT_PROF
-#define BT_TICK(slot) { const unsigned now__ = (unsigned)__builtin_amdgcn_s_memtime(); pacc[slot] += now__ - tprev; tprev = now__; }
-#elif defined(BT_MARKS)
-#define BT_TICK(slot) asm volatile("; BT_MARK " #slot);
-#else
-#define BT_TICK(slot)
-#endif
+// Round 6: the build switches of round 5 are frozen at the values that won (profiles/r05_msda_bwd_diet.txt has every pass) and
+// the timing-only ablation / phase-clock builds are gone; they are in the git history (`git log -- msda_bwd_mfma.hip`).
 
 namespace vllm {
 namespace {
 
-#ifdef BT_PROF
-__device__ unsigned long long g_bm_prof[16];   // phase clock of the diagnostics build (tools/msda_bwd_ablate.sh): ticks of wave 0 of every block
-#endif
 
 constexpr int BT_THREADS = 256;
 constexpr int BT_QPP = BT_THREADS / 8;   // 32 queries per pass (8 lanes x 4 channels = D 32)
 constexpr int BT_MAXL = 8;
-#ifndef BT_TILE_W
-#define BT_TILE_W 8
-#endif
-#ifndef BT_BLOCKS_PER_CU
-#define BT_BLOCKS_PER_CU 3
-#endif
-#ifndef BT_STAGE_C       // 1: a window of up to ~130 pixels is copied into LDS (LDS-DMA, behind the first round's scatter) and phase C reads its
-#define BT_STAGE_C 1     //    corners there, after the rounds (128 B / clock instead of the L1's 64); 0: phase C from global memory, before the barrier
-#endif
-#ifndef BT_PRIO           // wave priority while a wave feeds the matrix core and flushes (its block's other phases, and the other blocks', wait less
-#define BT_PRIO 2         // for the round to end): -2 %
-#endif
-#ifndef BT_CULL          // 1: the grad_value product skips the k-steps (groups of 8 query slots) that have no corner in the wave's 32 pixels
-#define BT_CULL 1
-#endif
+constexpr int BT_TILE_W = 8;          // 8 x 8 query tiles
+constexpr int BT_BLOCKS_PER_CU = 3;   // 33 KiB of LDS, 168 registers
+constexpr int BT_PRIO = 2;            // wave priority while a wave feeds the matrix core and flushes (its block's other phases, and the other blocks', wait less for the round to end): -2 %
+// (a window of up to ~130 pixels is copied into LDS -- LDS-DMA, behind the first round's scatter -- and phase C reads its corners
+//  there, after the rounds: 128 B / clock instead of the L1's 64; the grad_value product skips the k-steps -- groups of 8 query
+//  slots -- that have no corner in the wave's 32 pixels)
 constexpr int BT_TH = 8, BT_TW = BT_TILE_W, BT_NQ = BT_TH * BT_TW, BT_NPASS = BT_NQ / BT_QPP;
 constexpr int BT_R = 128;                 // window pixels per round (4 waves x one 32-pixel chunk)
 constexpr int BT_RP = BT_R + 1;           // row pitch of S^T [query][pixel] in floats (odd: the scatter's banks spread)
-#ifndef BT_MAXWIN_PX
-#define BT_MAXWIN_PX 8192
-#endif
-constexpr int BT_MAXWIN = BT_MAXWIN_PX;   // larger windows (a tile of coarse-level queries on a fine map: few points on many pixels): one atomic per (point, corner, channel), two whole pixel rows per wave instruction
+constexpr int BT_MAXWIN = 8192;   // larger windows (a tile of coarse-level queries on a fine map: few points on many pixels): one atomic per (point, corner, channel), two whole pixel rows per wave instruction
 constexpr size_t BT_LDS_ST = (size_t)BT_NQ * BT_RP * 4 + 16;   // S^T
-constexpr int BT_STG_PX = BT_STAGE_C ? 150 : 0;                 // staged window incl. its guards: 18.75 KiB (3 blocks per CU: 3 x 52 KiB, whatever the allocation granule)
+constexpr int BT_STG_PX = 150;                 // staged window incl. its guards: 18.75 KiB (3 blocks per CU: 3 x 52 KiB, whatever the allocation granule)
 constexpr size_t BT_LDS = BT_LDS_ST + (size_t)BT_STG_PX * 128;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef int int2_t __attribute__((ext_vector_type(2)));
@@ -176,10 +148,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
         s_geo_ok = (cum == (long)Lq);
     }
     __syncthreads();
-#ifdef BT_PROF
-    unsigned pacc[16] = {};
-    unsigned tprev = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
     const bool geo = uni(s_geo_ok) != 0;
     const int n_tiles = uni(geo ? s_tc[L] : (Lq + BT_TW - 1) / BT_TW);
     const unsigned n_items = (unsigned)B * (unsigned)M * (unsigned)n_tiles;   // (< 2^31: the launchers' precondition B M Lq < 2^31)
@@ -287,12 +255,10 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
         };
         load_gor();
 
-        BT_TICK(0)   // item set-up: decode, grad_output / first level's locations requested
         for (int l = 0; l < L; ++l) {
             const int H = uni(s_H[l]), W = uni(s_W[l]);
             const long lbase = (b * (long)S + uni(s_v0[l])) * MD + (long)m * D;   // (batch, level, head) origin, channel 0
 
-            BT_TICK(1)
 
             // ---- A: this lane's point (kpt) of each of its 4 queries; exact bounding window of all corners ----
             float him[BT_NPASS], wim[BT_NPASS], awp[BT_NPASS];
@@ -370,7 +336,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     }
                     const float4_t g = go[p];
                     float R[4][4];
-                    if (!(BT_ABL & 8)) { BT_STEP(0) BT_STEP(1) BT_STEP(2) BT_STEP(3) }
+                    BT_STEP(0) BT_STEP(1) BT_STEP(2) BT_STEP(3)
                     float kd[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -384,7 +350,7 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     const float d1 = (u0 && c0) ? kd[0] : 0.f, d2 = (u0 && c1) ? kd[1] : 0.f, d3 = (u1 && c0) ? kd[2] : 0.f, d4 = (u1 && c1) ? kd[3] : 0.f;
                     // every slot of a real query is written (a rejected point: zeros), so the two per-point gradients need no zero fill by
                     // the caller (vllm_msda_backward_f32_writes_point_grads); DCNv3: kh kw slots per query
-                    if ((sub & 2) == 0 && qok[p] && (!DCN || l * PT + kpt < DP) && !(BT_ABL & 16)) {
+                    if ((sub & 2) == 0 && qok[p] && (!DCN || l * PT + kpt < DP)) {
                         const long pi = DCN ? qidx[p] * DP + l * PT + kpt : (qidx[p] * L + l) * PT + kpt;
                         grad_attw[pi] = pok ? ((hh * hw) * d1 + (hh * lw) * d2) + ((lh * hw) * d3 + (lh * lw) * d4) : 0.f;
                         *reinterpret_cast<float2_t *>(grad_loc + 2 * pi) =
@@ -394,8 +360,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                 }
 #undef BT_STEP
             };
-            if (!BT_STAGE_C) phase_c(std::false_type{}, 0, 0, 0);
-            BT_TICK(4)   // C: corner reads, grad_loc / grad_attw
             int r2 = xmin, r3 = -xmax;
 #pragma unroll
             for (int p = 0; p < BT_NPASS; ++p) rhi[p] = -rhi[p];
@@ -413,7 +377,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             int (*red)[4] = s_red[red_par];
             red_par ^= 1;
             if (lane == 0) { red[wave][0] = r0; red[wave][1] = r1; red[wave][2] = r2; red[wave][3] = r3; }
-            BT_TICK(2)   // A: points + window reduction inside the wave
             __syncthreads();   // (also: every wave is done with the previous level pass -- S^T is zero again, the staging buffer has been read)
             const int y0 = uni(min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])));
             const int y1 = -uni(min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
@@ -423,12 +386,11 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
             const int npix = wh * ww;
             const bool use_win = npix <= BT_MAXWIN;   // block-uniform
             // phase C from LDS: the window fits the staging buffer with its guards (block-uniform)
-            const bool staged = BT_STAGE_C && y1 >= 0 && ((npix + 7) & ~7) + 2 * (ww + 1) <= BT_STG_PX;
+            const bool staged = y1 >= 0 && ((npix + 7) & ~7) + 2 * (ww + 1) <= BT_STG_PX;
             bool stage_waited = false;
-            BT_TICK(3)   // window barrier
             do {
             if (y1 < 0) break;   // no accepted point at this level (block-uniform): nothing for grad_value
-            if (staged && !(BT_ABL & 8)) {
+            if (staged) {
                 // the value window of this (batch, level, head) into LDS: 8 pixels (1 KiB) per wave instruction, LDS-DMA; it only holds
                 // pixels of the map (its box comes from clamped corners).  Waited for in front of the first round's barrier.
                 const unsigned ww_m = (1u << 20) / (unsigned)ww + 1u;
@@ -440,7 +402,6 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                                                      (__attribute__((address_space(3))) void *)(smem + BT_LDS_ST + (ww + 1) * 128 + p0 * 128), 16, 0, 0);
                 }
             }
-            if (BT_ABL & 64) break;
 
             // ---- D: grad_value of this level: rounds of 128 window pixels ----
             __attribute__((address_space(3))) float *st3 = (__attribute__((address_space(3))) float *)st;
@@ -477,13 +438,12 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     for (int e8 = 0; e8 < PT * 2; ++e8) {
                         const uint2_t a = toff[slot * (PT * 2) + e8];
                         const float2_t w = twt[slot * (PT * 2) + e8];
-                        if (w.x != 0.f && !(BT_ABL & 2)) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.x), w.x * gval);
-                        if (w.y != 0.f && !(BT_ABL & 2)) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.y), w.y * gval);
+                        if (w.x != 0.f) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.x), w.x * gval);
+                        if (w.y != 0.f) unsafeAtomicAdd(reinterpret_cast<float *>(gsl + (size_t)a.y), w.y * gval);
                     }
                 }
                 __syncthreads();
                 for (int i = tid; i < BT_NQ * PT * 2; i += BT_THREADS) reinterpret_cast<float4_t *>(smem)[i] = (float4_t){0.f, 0.f, 0.f, 0.f};   // S^T is zero again
-                BT_TICK(7)
                 break;
             }
             for (int base = 0; base < npix; base += BT_R) {
@@ -507,14 +467,11 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     const int row = (p * BT_QPP + slot0) * BT_RP;
                     const int i1 = (hl - y0) * ww + (wl - x0w) - base, i2 = i1 + 1;
                     // (predicated, not redirected to a pad word: atomics of several lanes on one word would serialise)
-                    if (!(BT_ABL & 4)) {
-                        if (ur && c0 && (unsigned)i1 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i1, (wy_ * (1.f - lw)) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (ur && c1 && (unsigned)i2 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i2, (wy_ * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    if (ur && c0 && (unsigned)i1 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i1, (wy_ * (1.f - lw)) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ur && c1 && (unsigned)i2 < (unsigned)BT_R) __hip_atomic_fetch_add(st3 + row + i2, (wy_ * lw) * aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (staged && !stage_waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stage_waited = true; }   // this wave's part of the window has landed
                 __syncthreads();
-                BT_TICK(6)   // scatter + barrier
                 // (2) this wave's 32-pixel chunk x grad_out on the matrix cores, (3) atomics straight from the accumulator layout
                 const int p0 = base + wave * 32;
                 if (BT_PRIO) __builtin_amdgcn_s_setprio(BT_PRIO);
@@ -524,13 +481,13 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     asm volatile("" : "+v"(acc));   // (an accumulator in registers on every path: a constant-zero first product makes the skip paths re-materialise it)
                     const unsigned ap_lds = (unsigned)(uintptr_t)(st3 + hi * BT_RP + wave * 32 + l31);   // (this wave is the only reader of its 32 columns: it zeroes what it has read)
-                    if (!(BT_ABL & 32)) {
+                    {
                         // only the k-steps whose queries have a corner in this chunk's pixel rows: group g of 8 slots (4 k-steps) touches the
                         // linear window pixels [(first row - y0) ww, (last row - y0 + 1) ww)
                         const int2_t rr = rows[lane & (BT_NQ / 8 - 1)];
                         const int glo = (rr.x - y0) * ww, ghi = (-rr.y - y0 + 1) * ww;
                         const bool hit = rr.y <= 0 && glo < p0 + 32 && ghi > p0;
-                        const unsigned gmask = (BT_CULL ? (unsigned)__ballot(hit && lane < BT_NQ / 8) : 0xffffffffu);
+                        const unsigned gmask = (unsigned)__ballot(hit && lane < BT_NQ / 8);
 #pragma unroll
                         for (int g8 = 0; g8 < BT_NQ / 8; ++g8) {
                             if (gmask & (1u << g8)) {
@@ -562,37 +519,20 @@ __global__ __launch_bounds__(BT_THREADS, BT_BLOCKS_PER_CU) void msda_bwd_mfma_ke
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float a = acc[4 * j4 + i];
-                            if (a != 0.f && !(BT_ABL & 1) && !((BT_ABL & 256) && (i & 1)) && !((BT_ABL & 1024) && dscale != 12345.f)) {   // (1024: the product is computed, nothing is flushed)
-                                const unsigned po_i = (BT_ABL & 512) ? (po[i] & 0xfff80u) : po[i];   // (timing only: 256 every second atomic, 512 all of them inside 1 MiB)
-                                float *dst = reinterpret_cast<float *>(gfl + (size_t)(po_i + (unsigned)l31 * 4u));
-                                if (BT_ABL & 128) *dst = a;   // (timing only: plain stores)
-                                else unsafeAtomicAdd(dst, a);
-                            }
+                            if (a != 0.f) unsafeAtomicAdd(reinterpret_cast<float *>(gfl + (size_t)(po[i] + (unsigned)l31 * 4u)), a);
                         }
                     }
                 }
                 if (BT_PRIO) __builtin_amdgcn_s_setprio(0);
-                BT_TICK(7)   // MFMA + flush
                 if (base + BT_R < npix) __syncthreads();   // another round: every wave has read (and zeroed) its columns before the next scatter
-                BT_TICK(11)
             }
-#ifdef BT_PROF
-            pacc[9] += 1; pacc[10] += (unsigned)npix;
-#endif
             } while (0);
-            if (BT_STAGE_C) {
-                if (staged) {
-                    if (!stage_waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (no round ran: ablation builds only)
-                    phase_c(std::true_type{}, y0, x0w, ww);
-                } else phase_c(std::false_type{}, 0, 0, 0);
-                BT_TICK(4)
-            }
+            if (staged) {
+                if (!stage_waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (no round ran)
+                phase_c(std::true_type{}, y0, x0w, ww);
+            } else phase_c(std::false_type{}, 0, 0, 0);
         }
     }
-#ifdef BT_PROF
-    if (tid == 0)
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_bm_prof[i], (unsigned long long)pacc[i]);
-#endif
 }
 
 }  // namespace
@@ -643,24 +583,5 @@ int dcnv3_bwd_mfma_launch(const float *input, const float *offset, const float *
     return VLLM_OK;
 }
 
-#ifdef BT_ABL_ENTRY
-extern "C" int bt_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw,
-                          const float *grad_out, int B, int S, int M, int L, int Lq, float *gv, float *gl, float *gw, void *stream)
-{
-    return msda_bwd_mfma_launch(value, shapes, lsi, loc, attw, grad_out, B, S, M, L, Lq, gv, gl, gw, (hipStream_t)stream);
-}
-void set_error(const char *, ...) {}
-#ifdef BT_PROF
-extern "C" int bt_abl_prof(long *out)
-{
-    unsigned long long h[16];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bm_prof), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < 16; ++i) out[i] = (long)h[i];
-    const unsigned long long z[16] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bm_prof), z, sizeof(z));
-    return 0;
-}
-#endif
-#endif
 
 }  // namespace vllm

@@ -29,32 +29,14 @@
 #include "msda_sample.hpp"
 #include "msda_tiled6_helpers.hpp"
 
-// Timing-only ablation builds: -DT9_ABL=<mask>.  1: no multiply-adds in the gather, 2: no LDS reads in the gather,
-// 4: no window DMA, 8: no output stores, 16: no gather at all, 32: no point arithmetic (P1 skipped), 64: conflict-free gather reads.
-#ifndef T9_EARLY      // levels of pass 0 a team gathers at the END of its preparing half (behind a meeting point of its own), 0: none
-#define T9_EARLY 3     // (round 5: with the leaner preparing half three levels balance the halves: 410.9 vs 432.0 us with one, profiles/r05_msda_diet.txt)
-#endif
-#ifndef T9_ABL
-#define T9_ABL 0
-#endif
-#ifndef T9_ASM_STORE  // 1: the output stores are inline assembly (no compiler-inserted vmcnt(0) in front of the next pass); 0: plain stores
-#define T9_ASM_STORE 0
-#endif
-#ifndef T9_WAITCNT    // s_waitcnt lgkmcnt(N) that releases the older register set: 8 by construction; 7 = experiment (race screen)
-#define T9_WAITCNT 8
-#endif
-#ifndef T9_TW         // waves per team: 4 (8 waves, 2 per SIMD, 3 passes of 64 slots) or 6 (12 waves, 3 per SIMD, 2 passes of 96 slots:
-#define T9_TW 6       // generation 8's shape with this file's straight-line halves and pipelined gather): the library's build
-#endif
-#ifndef T9_DIET       // round 5, instruction diet of the preparing half (bit mask; profiles/r05_msda_diet.txt): 1 incremental window DMA,
-#define T9_DIET 63    // 2 leaner point arithmetic + packed box minima, 4 item decode by multiply-high, 8 six-product weights, 16 contiguous DMA runs per wave, 32 layout fast path + reciprocal magic, (64: slot words carried in a register -- spills 3 VGPRs, not in the default)
-#endif
-#ifndef T9_COLD_PIPE  // 1 (round 5): the global-memory levels' points two deep in flight; 0: the rolled loop of round 4
-#define T9_COLD_PIPE 1
-#endif
-#ifndef T9_GPRIO      // s_setprio of a wave while it gathers
-#define T9_GPRIO 2
-#endif
+// Round 6: the build switches of rounds 4-5 are frozen at the values that won (instruction diet of the preparing half: all of
+// it but the register-carried slot words; global-memory levels two points deep in flight; plain output stores) and the timing-only
+// ablation builds are gone -- the losing sides and the ablation code are in the git history (`git log -- msda_tiled9.hip`,
+// profiles/r05_msda_diet.txt has their numbers); tools/freeze_ifdefs.py is how the conditionals were resolved.
+constexpr int T9_EARLY = 3;     // levels of pass 0 a team gathers at the END of its preparing half (behind a meeting point of its own): 410.9 vs 432.0 us with one
+constexpr int T9_WAITCNT = 8;   // s_waitcnt lgkmcnt(N) that releases the older register set: 8 by construction
+constexpr int T9_TW = 6;        // waves per team: 12 waves, 3 per SIMD, 2 passes of 96 slots
+constexpr int T9_GPRIO = 2;     // s_setprio of a wave while it gathers
 
 namespace vllm {
 
@@ -74,11 +56,6 @@ struct T9Set {
 };
 __device__ __forceinline__ void t9_read(T9Set &s, int b0, int b0p, int b1, int b1p)
 {
-    if (T9_ABL & 2) {
-        asm volatile("; no reads" : "=&v"(s.a1), "=&v"(s.a2), "=&v"(s.a3), "=&v"(s.a4), "=&v"(s.c1), "=&v"(s.c2), "=&v"(s.c3), "=&v"(s.c4)
-                     : "v"(b0), "v"(b0p), "v"(b1), "v"(b1p));
-        return;
-    }
     asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:128\n\t"
                  "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:128\n\t"
                  "ds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:128\n\t"
@@ -95,7 +72,6 @@ template <int CNT>
 __device__ __forceinline__ void t9_wait(T9Set &s)
 {
     static_assert(CNT == 0 || CNT == T9_WAITCNT, "two register sets of eight reads each");
-    if (T9_ABL & 2) return;
     if constexpr (CNT != 0)
         asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(s.a1), "+v"(s.a2), "+v"(s.a3), "+v"(s.a4), "+v"(s.c1), "+v"(s.c2), "+v"(s.c3), "+v"(s.c4) : "n"(T9_WAITCNT));
     else
@@ -110,15 +86,11 @@ struct T9Acc {
 };
 __device__ __forceinline__ void t9_fma(T9Acc &a, const T9Set &s, float e1, float e2, float e3, float e4)
 {
-    if (T9_ABL & 1) {
-        a.t0.x += s.a1[0] + s.a2[1] + s.a3[2] + s.a4[3] + e1; a.u0.x += s.c1[0] + s.c2[1] + s.c3[2] + s.c4[3] + e2 + e3 + e4;
-    } else {
 #define T9_CORNER(E, A, C)                                                                              \
-        a.t0 = t6_fma2(E, (float2_t){A[0], A[1]}, a.t0); a.u0 = t6_fma2(E, (float2_t){C[0], C[1]}, a.u0);   \
-        a.t1 = t6_fma2(E, (float2_t){A[2], A[3]}, a.t1); a.u1 = t6_fma2(E, (float2_t){C[2], C[3]}, a.u1);
-        T9_CORNER(e1, s.a1, s.c1) T9_CORNER(e2, s.a2, s.c2) T9_CORNER(e3, s.a3, s.c3) T9_CORNER(e4, s.a4, s.c4)
+    a.t0 = t6_fma2(E, (float2_t){A[0], A[1]}, a.t0); a.u0 = t6_fma2(E, (float2_t){C[0], C[1]}, a.u0);   \
+    a.t1 = t6_fma2(E, (float2_t){A[2], A[3]}, a.t1); a.u1 = t6_fma2(E, (float2_t){C[2], C[3]}, a.u1);
+    T9_CORNER(e1, s.a1, s.c1) T9_CORNER(e2, s.a2, s.c2) T9_CORNER(e3, s.a3, s.c3) T9_CORNER(e4, s.a4, s.c4)
 #undef T9_CORNER
-    }
     asm volatile("" : "+v"(a.t0), "+v"(a.t1), "+v"(a.u0), "+v"(a.u1));
 }
 
@@ -176,11 +148,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         return rr | ((lo >> (4 - rr)) << 2) | ((lo & ((16 >> rr) - 1)) << 6) | ((s >= n_slots ? 1 : 0) << 10);
     };
     const int v0k = (int)lsi[min(lane & 3, L - 1)];   // (the one per-lane constant that is a memory load: carried)
-#if T9_DIET & 64
-    // (round 5: the lane's two slot words, 11 bits each, carried in ONE register instead of re-derived per item: ~25 VALU per pass)
-    int sinfo_pk = 0;
-    if (NP == 2) sinfo_pk = sinfo_of(0, lane) | (sinfo_of(1, lane) << 11);
-#endif
 
     for (int i = tid; i < T6_ZPX * 32; i += THREADS) reinterpret_cast<float *>(smem)[i] = 0.f;
     if (tid < 32) s_box[tid] = T6_BIG;
@@ -207,7 +174,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         const int q = ok ? sQ + y * sW + x : (ty * 8) * W0 + tx * 16;
         return (unsigned)((b * Lq + q) * M + m);
     };
-#if T9_DIET & 4
     // Round 5: the three divisions of an item number (block-uniform, once per item and wave: ~25 scalar / vector instructions each
     // through the compiler's reciprocal sequence) by multiply-high with magic numbers made once per launch.  floor(n / d) ==
     // mulhi(n, floor(2^32 / d) + 1) for n * d < 2^32; every dividend here is < n_items and n_items * max(d) < 2^32 is checked
@@ -217,10 +183,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     const unsigned mg_M = fastdiv ? (unsigned)(0xffffffffu / (unsigned)M) + 1u : 0u;
     const unsigned mg_ntx = fastdiv ? (unsigned)(0xffffffffu / (unsigned)ntx0) + 1u : 0u;
     auto udiv = [](unsigned n, unsigned d, unsigned mg) { return mg ? __umulhi(n, mg) : n / d; };
-#else
-    auto udiv = [](unsigned n, unsigned d, unsigned) { return n / d; };
-    const unsigned mg_tiles = 0, mg_M = 0, mg_ntx = 0;
-#endif
     auto decode = [&](unsigned item, int &b, int &m, int &ty, int &tx) {
         const unsigned bm = udiv(item, (unsigned)n_tiles, mg_tiles), t = item - bm * (unsigned)n_tiles;
         const unsigned bb = udiv(bm, (unsigned)M, mg_M), yy = udiv(t, (unsigned)ntx0, mg_ntx);
@@ -245,11 +207,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             const int kk = min(ln & 3, L - 1);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-#if T9_DIET & 64
-                npr[p] = pair_of(NP == 2 ? (sinfo_pk >> (11 * p)) & 0x7ff : sinfo_of(p, ln), nb, nm, ty, tx, nqok[p]);
-#else
                 npr[p] = pair_of(sinfo_of(p, ln), nb, nm, ty, tx, nqok[p]);
-#endif
                 const unsigned e = (npr[p] * (unsigned)L + (unsigned)kk) * PT;
                 lc0[p] = *reinterpret_cast<const float4_t *>(loc + (size_t)e * 2);
                 lc1[p] = *reinterpret_cast<const float4_t *>(loc + (size_t)e * 2 + 4);
@@ -281,7 +239,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         const int cA = chunk_of(ln), cA0 = cA + (int)lds_addr(smem);
         // (timing-only ablation 64: every quad reads a fixed pixel whose parity is its quad number's -- the four quads of a
         //  ds_read_b128 lane group then hit four different bank sets: what a conflict-free window layout would buy)
-        const int cfree = cA0 + (T6_ZPX + ((ln >> 2) & 1)) * 128;
         // (wave-uniform) which levels this call gathers, and their window pitch in bytes
         bool act[4];
         int pit[4];
@@ -298,7 +255,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         // newer reads are outstanding.
 #define T9_STEP(SET, I_, LQ, CNT, NX, NI, NLQ)                                                                    \
     {                                                                                                            \
-        int b0_ = (NX) ? ((T9_ABL & 64) ? (qbi<NLQ>(oc[NI]) & 0) + cfree : qbi<NLQ>(oc[NI]) + cA0) : 0, b1_ = b0_ ^ 64; \
+        int b0_ = (NX) ? qbi<NLQ>(oc[NI]) + cA0 : 0, b1_ = b0_ ^ 64;                                               \
         int b0p_ = b0_ + pit[NLQ], b1p_ = b1_ + pit[NLQ];                                                        \
         float e1 = qbf<LQ>(w1c[I_]), e2 = qbf<LQ>(w2c[I_]), e3 = qbf<LQ>(w3c[I_]), e4 = qbf<LQ>(w4c[I_]);        \
         asm volatile("" : "+v"(b0_), "+v"(b1_), "+v"(b0p_), "+v"(b1p_), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4)); \
@@ -309,7 +266,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     }
 #define T9_RD(SET, I_, LQ)                                                                                       \
     {                                                                                                            \
-        const int b0_ = (T9_ABL & 64) ? (qbi<LQ>(oc[I_]) & 0) + cfree : qbi<LQ>(oc[I_]) + cA0, b1_ = b0_ ^ 64;     \
+        const int b0_ = qbi<LQ>(oc[I_]) + cA0, b1_ = b0_ ^ 64;                                                   \
         t9_read(SET, b0_, b0_ + pit[LQ], b1_, b1_ + pit[LQ]);                                                    \
     }
         // NO control flow between a read and the wait that releases it.  A first version requested the next level's first two
@@ -319,7 +276,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         // whole pass, a few times in a thousand launches, only on inputs with late / global-memory levels (the paths with joins).
         // So: (1) all four levels staged (the common case): ONE straight-line pipeline over the 16 points of the pass; (2) anything
         // else: a self-contained pipeline per staged level (it drains at the level's end: one LDS round trip per level).
-        if (!(T9_ABL & 16)) {
+        {
             if (act[0] && act[1] && act[2] && act[3]) {
                 T9_RD(sa, 0, 0) T9_RD(sb, 1, 0)
                 T9_STEP(sa, 0, 0, T9_WAITCNT, true, 2, 0) T9_STEP(sb, 1, 0, T9_WAITCNT, true, 3, 0)
@@ -351,7 +308,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             const int Hc = EXACT ? H0 >> l : uni(s_dim[l]), Wc = EXACT ? W0 >> l : uni(s_dim[4 + l]);
             const float *vc = vbc + (size_t)__builtin_amdgcn_readlane(v0k, l) * MD;
             const int src = ((ln & ~3) | l) << 2;
-#if T9_COLD_PIPE
             // Round 5: the four points of a cold level as a two-deep pipeline -- the 8 loads of point i + 1 are in flight under the
             // multiply-adds of point i (two register sets of 32: the hot gather's sets are dead here).  The rolled loop of round 4
             // paid one global-memory round trip per point, 4 per level and pass, and a cold item (6.8 % of the bench's items) took two to
@@ -401,41 +357,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 cold_consume(cb);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#else
-            // (a ROLLED loop over the four points, the point's data picked by compares: this path runs for ~4 % of the items, and
-            //  unrolled the compiler keeps 32 loads x 4 registers in flight -- a budget the pipelined gather above needs)
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                const int oci = i == 0 ? oc[0] : i == 1 ? oc[1] : i == 2 ? oc[2] : oc[3];
-                const float w1i = i == 0 ? w1c[0] : i == 1 ? w1c[1] : i == 2 ? w1c[2] : w1c[3];
-                const float w2i = i == 0 ? w2c[0] : i == 1 ? w2c[1] : i == 2 ? w2c[2] : w2c[3];
-                const float w3i = i == 0 ? w3c[0] : i == 1 ? w3c[1] : i == 2 ? w3c[2] : w3c[3];
-                const float w4i = i == 0 ? w4c[0] : i == 1 ? w4c[1] : i == 2 ? w4c[2] : w4c[3];
-                const int hwp = __builtin_amdgcn_ds_bpermute(src, oci);
-                const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w1i)));
-                const float e2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w2i)));
-                const float e3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w3i)));
-                const float e4 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w4i)));
-                const int bh = (hwp >> 16) - 1, bw = (hwp & 0xffff) - 1;
-                const bool u0 = bh >= 0, u1 = bh + 1 <= Hc - 1, l0 = bw >= 0, l1 = bw + 1 <= Wc - 1;
-                const int h0 = min(max(bh, 0), Hc - 1), h1 = min(max(bh + 1, 0), Hc - 1);
-                const int c0 = min(max(bw, 0), Wc - 1), c1 = min(max(bw + 1, 0), Wc - 1);
-                const float *p1 = vc + (size_t)((unsigned)(h0 * Wc + c0) * MD), *p2 = vc + (size_t)((unsigned)(h0 * Wc + c1) * MD);
-                const float *p3 = vc + (size_t)((unsigned)(h1 * Wc + c0) * MD), *p4 = vc + (size_t)((unsigned)(h1 * Wc + c1) * MD);
-                const int eA = cA / 4, eB = (cA ^ 64) / 4;
-                const float4_t a1 = load4(p1 + eA), a2 = load4(p2 + eA), a3 = load4(p3 + eA), a4 = load4(p4 + eA);
-                const float4_t d1 = load4(p1 + eB), d2 = load4(p2 + eB), d3 = load4(p3 + eB), d4 = load4(p4 + eB);
-                const float f1 = (u0 && l0) ? e1 : 0.f, f2 = (u0 && l1) ? e2 : 0.f, f3 = (u1 && l0) ? e3 : 0.f, f4 = (u1 && l1) ? e4 : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[c] += f1 * ((u0 && l0) ? a1[c] : 0.f) + f2 * ((u0 && l1) ? a2[c] : 0.f) +
-                              f3 * ((u1 && l0) ? a3[c] : 0.f) + f4 * ((u1 && l1) ? a4[c] : 0.f);
-                    acc[4 + c] += f1 * ((u0 && l0) ? d1[c] : 0.f) + f2 * ((u0 && l1) ? d2[c] : 0.f) +
-                                  f3 * ((u1 && l0) ? d3[c] : 0.f) + f4 * ((u1 && l1) ? d4[c] : 0.f);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
             if (PROF) pacc[12] += 1;
         }
     };
@@ -445,7 +366,7 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
     // store's registers at issue; they are left alone for 16 wait states behind it (the margin gemm256p.hip measured).  The
     // compiler's own counted vmcnt waits stay correct: stores it does not know about can only make a wait longer.
     auto store_out = [&](const float (&acc)[8], bool qok, unsigned pr) {
-        if (qok && !(T9_ABL & 8)) {
+        if (qok) {
             const int cA = chunk_of(lane_now());
             if (out16) {   // the caller (the fused layer) wants the bf16 operand of output_proj
                 uint16_t *op = out16 + (size_t)pr * D;
@@ -453,18 +374,14 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 o1.x = pack_bf16x2(acc[0], acc[1]); o1.y = pack_bf16x2(acc[2], acc[3]);
                 o2.x = pack_bf16x2(acc[4], acc[5]); o2.y = pack_bf16x2(acc[6], acc[7]);
                 uint16_t *p1 = op + cA / 4, *p2 = op + (cA ^ 64) / 4;
-                if (T9_ASM_STORE)
-                    asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %2, %3, off\n\ts_nop 7\n\ts_nop 7"
-                                 :: "v"(p1), "v"(o1), "v"(p2), "v"(o2) : "memory");
-                else { *reinterpret_cast<uint2_t *>(p1) = o1; *reinterpret_cast<uint2_t *>(p2) = o2; }
+                *reinterpret_cast<uint2_t *>(p1) = o1;
+                *reinterpret_cast<uint2_t *>(p2) = o2;
             } else {
                 float *op = out + (size_t)pr * D;
                 const float4_t v1 = {acc[0], acc[1], acc[2], acc[3]}, v2 = {acc[4], acc[5], acc[6], acc[7]};
                 float *p1 = op + cA / 4, *p2 = op + (cA ^ 64) / 4;
-                if (T9_ASM_STORE)
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %2, %3, off\n\ts_nop 7\n\ts_nop 7"
-                                 :: "v"(p1), "v"(v1), "v"(p2), "v"(v2) : "memory");
-                else { store4(p1, v1); store4(p2, v2); }
+                store4(p1, v1);
+                store4(p2, v2);
             }
         }
     };
@@ -489,7 +406,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
         const int sub8 = ln & 7;
-#if T9_DIET & 16
         // Round 5, second step: a wave takes a CONTIGUOUS run of 8-pixel groups of the concatenated windows (call sites), here groups
         // [phase, np) of this level: with groups dealt round-robin every wave set up every level (4 x ~68 instructions per item,
         // twice the cost of the rounds themselves); a contiguous sixth of the list touches 1-2 levels.  The walk is the incremental
@@ -518,38 +434,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 voff += carry ? sCv : sNv;
             }
         }
-#elif T9_DIET & 1
-        // Round 5: the lane's pixel walks the window INCREMENTALLY.  Round 4 re-derived (row, column) of pixel pix0 + lane / 8 from
-        // scratch every round -- a magic-number division and two more 32-bit multiplies (quarter rate) plus a 64-bit multiply-add:
-        // 23 instructions per 1 KiB.  A round advances every lane by TW * 8 pixels = dq rows + dr columns (level constants); the
-        // column carries into the row at most once (dr < ww).  Rows outside the map fall outside the buffer descriptor (hardware
-        // zero fill, also for the wrapped "negative" offsets of row -1); only the column needs a test.  8 VALU + 1 load per round.
-        const int pixi = uni(g0) * 8 + (ln >> 3);
-        const int wy0 = (int)(__umul24((unsigned)pixi, magic) >> 20);          // (pixi < 64, magic <= 2^20 + 1: 24-bit operands, full rate)
-        int gx = x0 + (pixi - __mul24(wy0, ww));
-        unsigned voff = ((unsigned)(__mul24(y0 + wy0, Wl) + gx) * MD + (unsigned)sub8 * 4u) * 4u;
-        const int dq = (int)(((unsigned)(TW * 8) * magic) >> 20), dr = TW * 8 - dq * ww;   // (wave-uniform)
-        const unsigned stepN = (unsigned)(dq * Wl + dr) * (unsigned)uni((int)MD) * 4u;
-        const unsigned stepC = stepN + (unsigned)(Wl - ww) * (unsigned)uni((int)MD) * 4u;
-        const int xend = x0 + ww;
-        for (int pix0 = uni(g0) * 8; pix0 < np; pix0 += TW * 8) {
-            const unsigned vo = (unsigned)gx < (unsigned)Wl ? voff : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + pix0 * 128), 16, (int)vo, 0, 0, 0);
-            gx += dr;
-            const bool carry = gx >= xend;
-            gx -= carry ? ww : 0;
-            voff += carry ? stepC : stepN;
-        }
-#else
-        for (int pix0 = uni(g0) * 8; pix0 < np; pix0 += TW * 8) {
-            const int pix = pix0 + (ln >> 3);
-            const int wy = (int)(((unsigned)pix * magic) >> 20), wx = pix - wy * ww;
-            const int gy = y0 + wy, gx = x0 + wx;
-            const bool inside = (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
-            const unsigned voff = inside ? ((unsigned)(gy * Wl + gx) * MD + (unsigned)sub8 * 4u) * 4u : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst0 + pix0 * 128), 16, (int)voff, 0, 0, 0);
-        }
-#endif
     };
 
     // a team's meeting point: wait until `target` arrivals have been counted.  Bounded: the four waves of a team always take the
@@ -592,10 +476,9 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(w1[p][i]), "=v"(w2[p][i]), "=v"(w3[p][i]), "=v"(w4[p][i]), "=v"(o[p][i]));
             const int lnA = lane_now();
             const int k = lnA & 3;                       // the value level this lane owns
-            if (cv && !(T9_ABL & 32)) {
+            if (cv) {
                 const int kk = min(k, L - 1);
                 const int Hk = EXACT ? H0 >> kk : s_dim[kk], Wk = EXACT ? W0 >> kk : s_dim[4 + kk];
-#if T9_DIET & 2
                 // Round 5 form of the point arithmetic (profiles/r05_msda_diet.txt: 53 -> ~34 instructions per point).  Same values
                 // as sample_point() for every accepted point: the acceptance test is the reference's four comparisons, floor() is
                 // taken once and reused as the float the fractions are measured from ((float)(int)floor(x) == floor(x) for the
@@ -619,16 +502,11 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                         const float lh = ok ? h_im - hf : 0.f, lw = ok ? w_im - wf : 0.f;
                         const float a = ok ? la[p][i] : 0.f;
                         const float hh = 1.f - lh, hw_ = 1.f - lw;
-#if T9_DIET & 8
                         // (six products instead of eight: the attention weight goes into the two row factors first.  One rounding
                         //  placed differently from the other kernels of the family, 1 ulp of a weight: inside the 2e-6 the tests
                         //  allow between kernels, 4e-6 against the oracle)
                         const float ta = hh * a, tb = lh * a;
                         w1[p][i] = ta * hw_; w2[p][i] = ta * lw; w3[p][i] = tb * hw_; w4[p][i] = tb * lw;
-#else
-                        w1[p][i] = (hh * hw_) * a; w2[p][i] = (hh * lw) * a;
-                        w3[p][i] = (lh * hw_) * a; w4[p][i] = (lh * lw) * a;
-#endif
                         const int oo = ok ? ((int)hf << 16) + (int)wf + 0x10001 : -1;
                         o[p][i] = oo;
                         asm("v_pk_min_u16 %0, %1, %2" : "=v"(rmin) : "v"(rmin), "v"(oo));
@@ -649,36 +527,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     asm volatile("ds_min_i32 %0, %1\n\tds_min_i32 %0, %2 offset:4\n\tds_min_i32 %0, %3 offset:8\n\tds_min_i32 %0, %4 offset:12"
                                  :: "v"(a), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
                 }
-#else
-                int r0 = T6_BIG, r1 = T6_BIG, r2 = T6_BIG, r3 = T6_BIG;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    unsigned okm_ = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float lx = i < 2 ? lc0[p][2 * i] : lc1[p][2 * i - 4], ly = i < 2 ? lc0[p][2 * i + 1] : lc1[p][2 * i - 3];
-                        const SamplePoint<float> sp = sample_point<float>(lx, ly, Hk, Wk);
-                        const bool ok = sp.ok && qokc[p] && k < L;
-                        const float lh = sp.h_im - (float)sp.h_low, lw = sp.w_im - (float)sp.w_low;
-                        const float hh = 1.f - lh, hw_ = 1.f - lw;
-                        const float a = la[p][i];
-                        w1[p][i] = ok ? (hh * hw_) * a : 0.f; w2[p][i] = ok ? (hh * lw) * a : 0.f;
-                        w3[p][i] = ok ? (lh * hw_) * a : 0.f; w4[p][i] = ok ? (lh * lw) * a : 0.f;
-                        o[p][i] = ((sp.h_low + 1) << 16) | (sp.w_low + 1);
-                        okm_ |= ok ? (1u << i) : 0u;
-                        r0 = min(r0, ok ? sp.h_low : T6_BIG); r1 = min(r1, ok ? -sp.h_low : T6_BIG);
-                        r2 = min(r2, ok ? sp.w_low : T6_BIG); r3 = min(r3, ok ? -sp.w_low : T6_BIG);
-                    }
-                    okm[p] = okm_;
-                }
-                r0 = dpp_min<0x128>(dpp_min<0x124>(r0)); r1 = dpp_min<0x128>(dpp_min<0x124>(r1));   // row_ror:4, row_ror:8
-                r2 = dpp_min<0x128>(dpp_min<0x124>(r2)); r3 = dpp_min<0x128>(dpp_min<0x124>(r3));
-                if ((lnA & 12) == 0) {
-                    const unsigned a = lds_addr(s_box + team * 16 + k * 4);
-                    asm volatile("ds_min_i32 %0, %1\n\tds_min_i32 %0, %2 offset:4\n\tds_min_i32 %0, %3 offset:8\n\tds_min_i32 %0, %4 offset:12"
-                                 :: "v"(a), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
-                }
-#endif
             }
             T9_TICK(1)
             // ================= P2: layout beside the other team's item, LDS offsets, window DMA =================
@@ -698,14 +546,10 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                 const int wwk = (-bx.w + 1) - bx.z + 1;
                 int np8k = anyk ? ((((-bx.y + 1) - bx.x + 1) * wwk + 7) & ~7) : 0;
                 if (anyk && wwk > T6_ZPX - 2) np8k = 0x10000;
-#if T9_DIET & 32
                 // floor(2^20 / ww) + 1 through the hardware reciprocal: 2^20 / ww is an integer (ww a power of two: exact in float) or
                 // at least 1 / ww away from one on either side, the float result is within 2^20 / ww * 2^-22 = 1 / (4 ww) of it --
                 // the same number as the integer division (~20 instructions with four quarter-rate multiplies) for every ww >= 1
                 const unsigned magick = (unsigned)(1048576.f * __builtin_amdgcn_rcpf((float)max(wwk, 1))) + 1u;
-#else
-                const unsigned magick = (1u << 20) / (unsigned)max(wwk, 1) + 1u;
-#endif
                 int cum[5] = {0, 0, 0, 0, 0};
                 magick_c = magick;
                 {
@@ -716,7 +560,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     const int limit = R - used_other;
                     int used = 0, lays[4];
                     late_l = -1; late_np = 0;
-#if T9_DIET & 32
                     // Round 5: the common case -- every level fits beside the other team's item -- without the level-by-level
                     // scalar walk (~120 scalar instructions per wave and item): the inclusive prefix sum of the four window sizes
                     // on lanes 0 .. 3 (two DPP row shifts), one comparison of the total, bases / layout words computed on those
@@ -737,7 +580,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                         }
                         used = total;
                     } else
-#endif
                     {
 #pragma unroll
                     for (int l = 0; l < 4; ++l) {
@@ -771,26 +613,18 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                     for (int p = 0; p < NP; ++p)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-#if T9_DIET & 2
                             // (row * pitch by the 24-bit multiply-add -- full rate, the 32-bit product is quarter rate; the
                             //  constants of the level folded into one; rejected points carry a negative word)
                             const int cst = T6_ZPX + basek - (y0k + 1) * wwk - (x0k + 1);
                             const int lin = __mul24((int)((unsigned)o[p][i] >> 16), wwk) + (o[p][i] & 0xffff);   // (hl + 1) * ww + (wl + 1)
                             const int off = o[p][i] >= 0 ? (lin + cst) * 128 : 0;
                             o[p][i] = hotk ? off : o[p][i];
-#else
-                            const int hl = (o[p][i] >> 16) - 1, wl = (o[p][i] & 0xffff) - 1;
-                            const bool use = (okm[p] >> i) & 1u;
-                            const int off = use ? (T6_ZPX + basek + (hl - y0k) * wwk + (wl - x0k)) * 128 : 0;
-                            o[p][i] = hotk ? off : o[p][i];
-#endif
                         }
                 }
                 T9_TICK(2)   // layout + offsets
                 // window DMA: the hot windows are ONE concatenated list of 8-pixel groups, group g belongs to wave g % TW of the team
-                if (!(T9_ABL & 4)) {
+                {
                     const float *vbn = value + ((size_t)cb * S * M + cm) * D;
-#if T9_DIET & 16
                     const int n8 = uni(cum[4]) >> 3;                                   // groups of 8 pixels over all staged levels
                     const int ga = (wt * n8) / TW, gb = ((wt + 1) * n8) / TW;           // this wave's run
 #pragma unroll
@@ -799,13 +633,6 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
                         const int lo = max(ga, c0), hi = min(gb, c1);
                         if (lo < hi) dma_level(l, hi - c0, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick, lo - c0);
                     }
-#else
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) {
-                        const int np = uni(cum[l + 1]) - uni(cum[l]);
-                        if (np > 0) dma_level(l, np, __builtin_amdgcn_readlane(lay, l) & 0xffff, vbn, magick, (uni(cum[l]) >> 3) % TW);
-                    }
-#endif
                 }
                 T9_TICK(3)   // DMA issue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the windows has landed
@@ -840,14 +667,10 @@ __global__ __launch_bounds__(T9_TW * 128, 1) void msda_fwd_tiled9_kernel(
             if (cv) {
                 if (T9_GPRIO) __builtin_amdgcn_s_setprio(T9_GPRIO);   // the gathering wave goes first on the SIMD it shares with a preparing one
                 const bool has_late = uni(late_l) >= 0;   // (team-uniform)
-                if (has_late && !(T9_ABL & 4)) {          // its DMA goes out first and lands under pass 0 of the other levels
+                if (has_late) {          // its DMA goes out first and lands under pass 0 of the other levels
                     const float *vbc = value + ((size_t)cb * S * M + cm) * D;
-#if T9_DIET & 16
                     const int n8l = uni(late_np) >> 3;
                     dma_level(uni(late_l), ((wt + 1) * n8l) / TW, uni(late_base), vbc, magick_c, (wt * n8l) / TW);
-#else
-                    dma_level(uni(late_l), uni(late_np), uni(late_base), vbc, magick_c, 0);
-#endif
                 }
                 // The passes in a ROLLED loop over ONE copy of the gather (two with the late form): the gather always reads the
                 // registers of pass 0, and behind a pass the next one's point data move there (20 moves; pass 0's are dead by then.
@@ -950,13 +773,5 @@ int msda9_debug_counters(long *out, int n)
     return n < 16 ? n : 16;
 }
 
-#ifdef T9_ABL_ENTRY
-extern "C" int t9_abl_run(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attw, int B,
-                          int S, int M, int L, int Lq, float *out, void *stream)
-{
-    return msda_tiled9_launch(value, shapes, lsi, loc, attw, B, S, M, L, Lq, out, 0, (hipStream_t)stream, nullptr, 1, 1);
-}
-void set_error(const char *, ...) {}
-#endif
 
 }  // namespace vllm
