@@ -12,7 +12,7 @@ struct Dcnv3Geo {
 // disagree in the last bit of loc can disagree about a whole cell for a location next to an integer.  The empty asm
 // makes the product opaque (zero instructions), as mul_rn of msda_sample.hpp does for the MSDA kernels.
 // What this guarantees and what it does not: cell parity next to integer locations holds between THIS library's
-// kernels and against the numpy / C oracle (oracle/dcnv3.py, dcnv3_oracle.c round the product on its own too).  The reference's
+// kernels and against the test suite's numpy / C restatement of the reference (it rounds the product on its own too).  The reference's
 // compiled CUDA extension is built by nvcc with its default -fmad=true, which may contract p0 + (i*d + off) * scale into one FMA:
 // for a location within 1 ulp of an integer that build can pick the neighbouring cell (grad_offset then differs by a whole cell's
 // slope).  No reference build exists here to compare against (CUDA only); the half-precision fixture keeps its
