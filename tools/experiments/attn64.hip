@@ -1,7 +1,18 @@
-// NOT part of the library since the end of round 6 (it was built, tested -- 109 attention tests green with it forced on -- and
-// measured: 854 us against 641 for attn.hip at 40 x 25 x S1025 x d128, 175 against 78 at 40 x 16 x S577 x d64;
-// profiles/r06_attn64.txt has the timings and the issue-gap histogram of its ISA).  To rebuild: copy next to attn.hip, declare
-// `int cls_block` in AttnArgs, and call attn_fwd64_launch from attn_fwd_launch.
+// NOT part of the library since the end of round 6.  It was built in three steps, tested (95-109 attention tests green with it forced
+// on) and measured on MI355X at 40 x 25 x S1025 x d128 against attn.hip's 641-650 us:
+//   v0  whole-tile software pipeline (two generations of 64-key scores): 640 registers as the compiler allocates them, 128 spilled;
+//   v1  half-tile pipeline, compiler-placed fragment reads: 854 us (d 64, 40 x 16 x S577: 175 us against 78);
+//   v2  (this file) K fragments by inline assembly in two register sets with counted waits, one rescale branch per half tile at a
+//       point with no read in flight, two max chains: 883 us -- the fragment latency was not what the time is made of.
+// profiles/r06_attn64.txt: timings, the issue-gap histogram of the ISA and the phase clock of v2 (s_memtime, every wave): of a
+// wave's 130 K cycles per 16-tile block 15.7 % are prologue (Q, first tiles' DMA, first scores: nothing else runs on the SIMD),
+// 14.5 % the per-tile vmcnt(0) + block barrier (skew between four waves that no other wave covers), 4.4 % the epilogue, and the four
+// compute phases take 4.97 K cycles per 64-key tile against 2.05 K of MFMA pipe time -- 8.5 non-MFMA issues per MFMA where the
+// guide budgets 5.  What it would take: a persistent block loop with K / V / Q prefetched across block seams (the 20 % of
+// prologue + epilogue), hand-allocated AGPRs (the compiler keeps the score accumulators in AGPRs and copies them out: 32-44
+// v_accvgpr_read per half tile) and hand-placed fillers -- a hand-scheduled instruction stream.
+// To rebuild: copy next to attn.hip, declare `int cls_block` in AttnArgs, call attn_fwd64_launch from attn_fwd_launch (attn_variant
+// bits 11-12 = 2 in round 6), and route vllm_debug_counters to attn64_debug_counters for the phase clock (bit 13).
 //
 // Fused self-attention forward, the 64-rows-per-wave body (round 6).
 //
@@ -127,9 +138,22 @@ __device__ __forceinline__ void attn_class_row(const AttnArgs &a, int bh, int wa
 }
 
 
-template <int D, bool F16>
+__device__ unsigned long long g_a64_prof[8];   // phase clock (attn_variant bit 13): ticks of every wave, summed
+
+template <int D, bool F16, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnArgs a)
 {
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto tick = [&](int slot) {
+        if constexpr (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            pacc[slot] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (PROF) tprev = __builtin_amdgcn_s_memtime();
     constexpr int KS = D / 16;            // k-steps of the QK^T product
     constexpr int DB = D / 32;            // 32-wide output blocks
     constexpr int TILE = KVBLK * D * 2;   // bytes per K or V tile
@@ -235,30 +259,71 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnArgs a)
     typedef f32x16_t scores_t[2];         // [group]: the scores of one 32-key half tile
     uint32_t pk[2][8];                    // P of the current half tile, packed pairs: [group][register pair]
 
-    // S^T of one 32-key half of a K tile for both groups: every K fragment feeds two MFMAs
-    auto qk = [&](uint32_t ks_, int kb, scores_t &st) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[g][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = *(const __attribute__((address_space(3))) bf16x8_t *)(uintptr_t)(ks_ + kofs[ks] + kb * 32 * (D * 2));
-            st[0] = mfma16<F16>(kf, qf[0][ks], st[0]);
-            st[1] = mfma16<F16>(kf, qf[1][ks], st[1]);
+    // K fragments by inline assembly, four at a time into one of two register sets, with counted waits tied to the registers they
+    // release (the compiler serialises ds_read_b128 -> s_waitcnt lgkmcnt(0) -> MFMA through ONE register quad: with nothing else on the
+    // SIMD every fragment's LDS latency is then exposed).  Rules inherited from msda_tiled9.hip: no control flow between a request and
+    // its wait (a join may copy registers whose reads are still in flight), no "memory" clobber on the requests.
+    struct KSet { bf16x8_t f0, f1, f2, f3; };
+    auto req4 = [&](KSet &s_, uint32_t base, int ks0) {
+        const uint32_t a0 = base + kofs[ks0], a1 = base + kofs[ks0 + 1], a2 = base + kofs[ks0 + 2], a3 = base + kofs[ks0 + 3];
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                     : "=&v"(s_.f0), "=&v"(s_.f1), "=&v"(s_.f2), "=&v"(s_.f3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    };
+    auto wait4 = [&](KSet &s_, auto cnt_) {
+        constexpr int CNT = decltype(cnt_)::value;
+        if constexpr (CNT == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(s_.f0), "+v"(s_.f1), "+v"(s_.f2), "+v"(s_.f3));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s_.f0), "+v"(s_.f1), "+v"(s_.f2), "+v"(s_.f3));
+    };
+    constexpr std::integral_constant<int, 4> W4{};
+    constexpr std::integral_constant<int, 0> W0{};
+    // S^T of one 32-key half of a K tile for both groups: every K fragment feeds two MFMAs; the eight fragments are requested up
+    // front (the exponentials of the previous half tile are issued under their flight)
+    KSet ka, kb2;
+    auto qk_req = [&](uint32_t ks_, int kb) {
+        const uint32_t base = ks_ + kb * 32 * (D * 2);
+        req4(ka, base, 0);
+        req4(kb2, base, 4);
+    };
+    auto qk_mma = [&](scores_t &st) {
+        static_assert(KS == 8 || KS == 4, "two sets of four fragments (d 128) or one (d 64: the second set repeats the first)");
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        wait4(ka, W4);
+        st[0] = mfma16<F16>(ka.f0, qf[0][0], zero);
+        st[1] = mfma16<F16>(ka.f0, qf[1][0], zero);
+        st[0] = mfma16<F16>(ka.f1, qf[0][1], st[0]);
+        st[1] = mfma16<F16>(ka.f1, qf[1][1], st[1]);
+        st[0] = mfma16<F16>(ka.f2, qf[0][2], st[0]);
+        st[1] = mfma16<F16>(ka.f2, qf[1][2], st[1]);
+        st[0] = mfma16<F16>(ka.f3, qf[0][3], st[0]);
+        st[1] = mfma16<F16>(ka.f3, qf[1][3], st[1]);
+        wait4(kb2, W0);
+        if constexpr (KS == 8) {
+            st[0] = mfma16<F16>(kb2.f0, qf[0][4], st[0]);
+            st[1] = mfma16<F16>(kb2.f0, qf[1][4], st[1]);
+            st[0] = mfma16<F16>(kb2.f1, qf[0][5], st[0]);
+            st[1] = mfma16<F16>(kb2.f1, qf[1][5], st[1]);
+            st[0] = mfma16<F16>(kb2.f2, qf[0][6], st[0]);
+            st[1] = mfma16<F16>(kb2.f2, qf[1][6], st[1]);
+            st[0] = mfma16<F16>(kb2.f3, qf[0][7], st[0]);
+            st[1] = mfma16<F16>(kb2.f3, qf[1][7], st[1]);
         }
     };
-    // row maxima of a half tile (both groups), then ONE wave-uniform branch for the running-max update: with the deferred rescale it
-    // is rare after the first tiles, and a single branch keeps the maxima in the basic block of the P V they are issued next to
-    auto start = [&](scores_t &st) {
-        float mx[2];
+    // row maxima of a half tile (both groups): VALU only, issued next to the P V MFMAs
+    auto row_max = [&](scores_t &st, float (&mx)[2]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            float m = -1.0e30f;
+            float m0 = fmaxf(st[g][0], st[g][1]), m1 = fmaxf(st[g][2], st[g][3]);   // (two chains: half the dependent latency)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, st[g][r]);
-            mx[g] = halves_max(m) * c2;
+            for (int r = 4; r < 16; r += 4) {
+                m0 = fmaxf(m0, fmaxf(st[g][r], st[g][r + 1]));
+                m1 = fmaxf(m1, fmaxf(st[g][r + 2], st[g][r + 3]));
+            }
+            mx[g] = halves_max(fmaxf(m0, m1)) * c2;
         }
+    };
+    // ONE wave-uniform branch for the running-max update, at a point where no LDS read is in flight: with the deferred rescale it is
+    // rare after the first tiles
+    auto rescale = [&](const float (&mx)[2]) {
         if (__builtin_expect(!__all(mx[0] - m_run[0] <= THR && mx[1] - m_run[1] <= THR), 0)) {
             // (the empty volatile statement keeps the compiler from flattening this branch: it had turned the rescale of the 2 x D / 32
             //  accumulators into unconditional code -- 128 AGPR reads, 64 packed multiplies, 128 AGPR writes per half tile)
@@ -328,30 +393,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     scores_t sA, sB;
+    float mxA[2] = {0.f, 0.f}, mxB[2] = {0.f, 0.f};
     if (live) {
-        qk(kaddr(0), 0, sA);
-        start(sA);
+        qk_req(kaddr(0), 0);
+        qk_mma(sA);
+        row_max(sA, mxA);
     }
-    // tile t: [first half] scores of its second half next to the exponentials of its first half, then P V of the first half next to
-    // the maxima of the second; [second half] the same one half tile later, the scores being those of tile t + 1's first half
+    tick(0);
+    // tile t, first half:  [rescale for (t,0)] K fragments of (t,1) requested | exponentials of (t,0) | scores of (t,1) | P V of (t,0) next
+    // to the maxima of (t,1);  second half: the same one half tile later, the scores being those of tile t + 1's first half
     auto tile = [&](int t, auto last_) {
         constexpr bool LAST = decltype(last_)::value;
-        if (t > 0) {
-            // K(t+1) and V(t) (issued one tile ago) have landed for every wave; every wave is done with K(t-1) and V(t-1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        // K(t+1) and V(t) (issued one tile ago) have landed for every wave; every wave is done with K(t-1) and V(t-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tick(1);
         if (t + 2 < nkt) stage_kv<D, false, false>(kb_, a.k_ts, (t + 2) * KVBLK, Sk, kslot(t + 2), wave, lane, kvo);
         if (!LAST) stage_kv<D, true, false>(vb_, a.v_ts, (t + 1) * KVBLK, Sk, vslot(t + 1), wave, lane, vvo);
+        tick(2);
         if (live) {
-            qk(kaddr(t), 1, sB);          // MFMA stream           |  VALU stream
-            finish(sA);                   //                       |  exponentials of (t, 0)
-            pv(vaddr(t), 0);              // P V of (t, 0)          |
-            start(sB);                    //                       |  maxima of (t, 1)   (a rescale of O follows the P V in program order)
-            if (!LAST) qk(kaddr(t + 1), 0, sA);
+            rescale(mxA);
+            qk_req(kaddr(t), 1);
+            finish(sA);
+            qk_mma(sB);
+            tick(3);
+            pv(vaddr(t), 0);
+            row_max(sB, mxB);
+            tick(4);
+            rescale(mxB);
+            if (!LAST) qk_req(kaddr(t + 1), 0);
             finish(sB);
+            if (!LAST) qk_mma(sA);
+            tick(5);
             pv(vaddr(t), 1);
-            if (!LAST) start(sA);
+            if (!LAST) row_max(sA, mxA);
+            tick(6);
         }
     };
     for (int t = 0; t + 1 < nkt; ++t) tile(t, std::false_type{});
@@ -386,6 +462,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnArgs a)
         const int qr = row_w + row;
         if (qr < a.S) *reinterpret_cast<uint4_t *>(a.out + (((long)b * a.S + qr) * a.H + head) * D + cc * 8) = v;
     }
+    if constexpr (PROF) {
+        tick(7);
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_a64_prof[i], pacc[i]);
+    }
 }
 
 // a: kx / qx / cls_block set by the caller (attn_fwd_launch); requires (S - kx) % 64 == 0 and a 16-byte aligned output
@@ -402,6 +483,14 @@ int attn_fwd64_launch(AttnArgs a, int D, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd64_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd64_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
     }
+    if (attn_variant() & 8192) {      // phase clock build (bf16, d 128)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd64_kernel<128, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+        if (D == 128 && !a.f16) {
+            VLLM_LAUNCH((attn_fwd64_kernel<128, false, true>), grid, block, lds, st, a);
+            VLLM_CHECK_LAUNCH("attn_fwd64_kernel<prof>");
+            return VLLM_OK;
+        }
+    }
     if (D == 64) {
         if (a.f16) VLLM_LAUNCH((attn_fwd64_kernel<64, true>), grid, block, lds, st, a);
         else VLLM_LAUNCH((attn_fwd64_kernel<64, false>), grid, block, lds, st, a);
@@ -410,6 +499,16 @@ int attn_fwd64_launch(AttnArgs a, int D, hipStream_t st)
         else VLLM_LAUNCH((attn_fwd64_kernel<128, false>), grid, block, lds, st, a);
     }
     VLLM_CHECK_LAUNCH("attn_fwd64_kernel");
+    return VLLM_OK;
+}
+
+int attn64_debug_counters(long *out, int n)
+{
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_a64_prof), sizeof(h)) != hipSuccess) return VLLM_ELAUNCH;
+    for (int i = 0; i < n && i < 8; ++i) out[i] = (long)h[i];
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a64_prof), z, sizeof(z));
     return VLLM_OK;
 }
 
