@@ -22,17 +22,40 @@ KEYS = {"vitl": {"msda_fwd_tiled7": "msda", "msda_fwd_tiled8_kernel<1200, false,
                         "gemm256p_kernelILi1": "gemm", "gemm256_bf16_kernel<1,": "gemm", "gemm256_bf16_kernelILi1": "gemm"}}
 
 
+# round 6: the other in-step GEMMs.  qkv = the bias epilogue that CONSUMES a folded norm (template flag LNC = true); proj and fc2 are
+# the SAME instantiation (residual epilogue + statistics): told apart by the kernel dispatched in front of them.
+EXTRA = {"gemm256p_kernel<0, 4, true": "gemm_qkv", "gemm256p_kernel<0, 3, true": "gemm_qkv"}
+RESIDUAL = ("gemm256p_kernel<3, 4, false, 1", "gemm256p_kernel<3, 3, false, 1", "gemm256p_kernel<3, 4, false, 2", "gemm256p_kernel<3, 3, false, 2")
+
+
 def load(d):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(list)
     for path in f:
-        for r in csv.DictReader(open(path)):
-            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(open(path)))
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+        prev = ""
+        for r in rows:
+            kn = r["Kernel_Name"]
+            if any(p in kn for p in RESIDUAL):
+                # a layer is qkv, attention, proj, fc1, fc2: the residual GEMM behind the attention kernel is proj, the one behind
+                # an activation-epilogue GEMM is fc2
+                if "attn_fwd_kernel" in prev:
+                    kn = "RESIDUAL_proj " + kn
+                elif "gemm256p_kernel<1," in prev or "gemm256p_kernel<2," in prev:
+                    kn = "RESIDUAL_fc2 " + kn
+            if r["Kernel_Name"] != prev and r.get("Counter_Name"):
+                pass
+            prev_name = r["Kernel_Name"]
+            agg[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            prev = prev_name
     return agg
 
 
 def main(fetch_dir, write_dir, out, workload="vitl"):
-    KEY = KEYS[workload]
+    KEY = dict(KEYS[workload], **EXTRA)
+    KEY["RESIDUAL_proj "] = "gemm_proj"
+    KEY["RESIDUAL_fc2 "] = "gemm_fc2"
     res = {}
     raw = {}
     for d in (fetch_dir, write_dir):
