@@ -541,6 +541,51 @@ def test_attention_online_softmax_rescale_branch(D, attn_sched):
     close(out, ref, 1.5e-2, "attention with spiked keys")
 
 
+@pytest.mark.parametrize("D,S", [(64, 577), (128, 1025), (64, 65), (128, 129), (64, 193), (128, 257)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_class_token_as_initial_state_extremes(D, S, dtype):
+    """Round 6: for S = 64 n + 1 token 0 leaves the key tiling and becomes the INITIAL state of every query's online softmax
+    (m = q.k0 * c, l = 1, O = v0), and -- where the body rows leave a spare wave -- the class QUERY row moves into that wave.
+    The extremes of that state: head 0: key 0 dominates every query (the running maximum never moves off the initial one, the tiles
+    only add small terms); head 1: key 0 is far BELOW every other score (the first tile must rescale the initial state away);
+    head 2: random.  Query row 0 (the class row) gets a spike of its own.  Against the fp64 softmax, per element, in the same form
+    as test_attention_vs_oracle; both 16-bit types; with the split switched off the same inputs give the round-5 tiling's result
+    within the same bound."""
+    torch.manual_seed(S + D)
+    B, H = 2, 3
+    qkv = torch.randn(B, S, 3, H, D, device=DEV) * 0.5
+    u = torch.nn.functional.normalize(torch.randn(B, 1, H, D, device=DEV), dim=-1) * (3.0 * D ** 0.25)   # (q . k0) d^-1/2 = +-9 along it
+    qkv[:, :, 0, 0] += u[:, :, 0]
+    qkv[:, 0, 1, 0] = u[:, 0, 0]                   # head 0: key 0 along the direction every query shares -> by far the largest score
+    qkv[:, :, 0, 1] += u[:, :, 1]
+    qkv[:, 0, 1, 1] = -u[:, 0, 1]                  # head 1: key 0 far below the rest
+    qkv[:, S // 2, 1, 2] = 4.0 * qkv[:, 0, 0, 2]   # head 2: a key in a middle tile aligned with the CLASS query
+    qkv = qkv.to(dtype)
+    fn = _lib.lib().vllm_attn_fwd_qkvpacked_bf16 if dtype == torch.bfloat16 else _lib.lib().vllm_attn_fwd_qkvpacked_f16
+    outs = {}
+    for var in (32, 2 | 64 | 128):                 # automatic (split) / the same schedule without the split
+        old = _lib.set_option("attn_variant", var)
+        try:
+            out = torch.full((B, S, H, D), float("nan"), dtype=dtype, device=DEV)
+            _lib.check(fn(P(qkv), P(out), B, S, H, D, D ** -0.5, stream()))
+            outs[var] = out
+        finally:
+            _lib.set_option("attn_variant", old)
+    q, k, v = qkv.double().cpu().reshape(B, S, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)
+    p = torch.softmax((q * D ** -0.5) @ k.transpose(-2, -1), -1)
+    assert float(p[:, 0, :, 0].min()) > 0.5 and float(p[:, 1, :, 0].max()) < 1e-3      # the fixture does what it says
+    ref64 = (p @ v).transpose(1, 2)
+    mag = (p @ v.abs()).transpose(1, 2)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    mant = 7 if dtype == torch.bfloat16 else 10
+    for var, out in outs.items():
+        assert torch.isfinite(out.float()).all()
+        err = (out.double().cpu() - ref64).abs()
+        ulp = 2.0 ** (torch.floor(torch.log2(ref64.abs().clamp_min(2.0 ** -14))) - mant)
+        worst = ((err - eps * mag).clamp_min(0) / ulp).max().item()
+        assert worst <= 1.0, f"attn_variant {var} D{D} S{S} {dtype}: {worst:.2f} ulp beyond the bound"
+
+
 # 0 plain (no deferred rescale, stores from the accumulators), 2 deferred rescale, 18 no padding trim (no class-token split), 66 = what
 # "automatic" selects, 194 the same WITHOUT the class-token split (the round-5 tiling), 1090 class token out of the KEY tiling only
 @pytest.mark.parametrize("variant", [0, 2, 18, 66, 194, 1090])
