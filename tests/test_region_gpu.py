@@ -36,6 +36,34 @@ def test_point_sample_vs_oracle(N, C, H, W, P):
                                rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,C,H,W,P", [(16, 384, 24, 24, 2304), (3, 100, 5, 7, 300), (2, 9, 80, 80, 500), (2, 200, 24, 24, 64)])
+def test_masked_mean_pixel_weight_form(N, C, H, W, P):
+    """Round 6: the fused masked mean runs as a pixel-weight product (the points' corner weights scattered once into H W accumulators
+    as 2^40-scaled integers, then one dot product per channel) -- the region encoder's shape, an odd map (scalar path: H W % 4 != 0), a
+    map too large for the LDS accumulators (the point-walk fallback), few points.  Against the oracle's sample-then-mean; repeated
+    launches bit-identical (integer atomics commute); a region without a valid point gives zeros; a NaN at a pixel that no valid
+    point touches does not leak through its zero weight."""
+    torch.manual_seed(N + C + H)
+    x = torch.randn(N, C, H, W)
+    c = torch.rand(N, P, 2) * 1.2 - 0.1
+    v = torch.rand(N, P) > 0.3
+    v[N - 1] = False                                           # the last region: no valid point
+    ref = O.masked_mean(O.point_sample(x, c), v)
+    out = A.point_sample_masked_mean(x.to(DEV), c.to(DEV), v.to(DEV))
+    assert torch.equal(out[N - 1].cpu(), torch.zeros(C)) and torch.isfinite(out).all()
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    for _ in range(3):
+        assert torch.equal(A.point_sample_masked_mean(x.to(DEV), c.to(DEV), v.to(DEV)), out)
+    # every valid point of region 0 in the lower right quadrant; a NaN in the upper left corner pixel of every plane of region 0
+    c2, v2, x2 = c.clone(), v.clone(), x.clone()
+    c2[0] = 0.55 + 0.4 * torch.rand(P, 2)
+    v2[0] = True
+    x2[0, :, 0, 0] = float("nan")
+    out2 = A.point_sample_masked_mean(x2.to(DEV), c2.to(DEV), v2.to(DEV))
+    assert torch.isfinite(out2[0]).all()
+    torch.testing.assert_close(out2[0].cpu(), O.masked_mean(O.point_sample(x, c2), v2)[0], rtol=1e-4, atol=1e-5)
+
+
 def test_nonfinite_coordinates_and_data():
     x = torch.randn(1, 4, 5, 5)
     c = torch.tensor([[[float("nan"), 0.5], [float("inf"), 0.5], [0.5, -float("inf")], [0.5, 0.5], [5.0, 5.0]]])
