@@ -17,9 +17,6 @@
 // (dcnv3.hip) to fp32 rounding (the mask value is folded into the weights).
 #include "common.hpp"
 #include "dcnv3_geo.hpp"
-#ifndef DP_ABLATE
-#define DP_ABLATE 0   // timing-only builds (results wrong): 1 no window DMA, 2 no corner reads / multiply-adds, 3 neither
-#endif
 
 namespace vllm {
 namespace {
@@ -256,7 +253,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
         DP_TICK(3)   // window geometry + offsets + prefetch issue
         // DMA of next's window: one round (PPW pixels per wave) per call, issued between the points of the gather
         // next's window DMA starts here (the previous one has landed: vmcnt(0) before the barrier)
-        d_on = nv && nhot && nnpix > 0 && !(DP_ABLATE & 1);
+        d_on = nv && nhot && nnpix > 0;
         if (d_on) {
             d_i0 = wave * PPW; d_npix = nnpix; d_y0 = ny0; d_x0 = nx0; d_ww = nww; d_buf = nbuf;
             d_slab = in + (long)nxt.b * q.H * q.W * GC + (long)nxt.g * CPG;
@@ -287,7 +284,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
                 if (cur_hot) {
                     const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char *)smem + pr_s * 128 + pr_rank * 32 + pr_p * 16;
 #define DP_POINT(R_, LQ)                                                                                          \
-    if (LQ + 4 * R_ < K && !(DP_ABLATE & 2)) {                                                                    \
+    if (LQ + 4 * R_ < K) {                                                                                         \
         const int t0 = dp_qbi<LQ>(pc.top[R_]) + lbase, t1 = t0 ^ 32, t2 = t0 ^ 64, t3 = t0 ^ 96;                  \
         const int b0 = dp_qbi<LQ>(pc.bot[R_]) + lbase, b1 = b0 ^ 32, b2 = b0 ^ 64, b3 = b0 ^ 96;                  \
         float4_t a0, a1, a2, a3, c0, c1, c2, c3;                                                                  \
@@ -377,7 +374,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
                 if (cur_hot) {
                     const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char *)smem + so;
     #define DP_POINT(R_, LQ)                                                                                          \
-        if (LQ + 4 * R_ < K && !(DP_ABLATE & 2)) {                                                                                        \
+        if (LQ + 4 * R_ < K) {                                                                                                            \
             const int t0 = dp_qbi<LQ>(pc.top[R_]) + lbase, t1 = dp_qbi<LQ>(pc.bot[R_]) + lbase;                       \
             float4_t a1, a2, a3, a4, c1, c2, c3, c4;                                                                  \
             /* the reads are ISSUED here and WAITED for after the DMA round: the round's address arithmetic and the issue stall */ \
