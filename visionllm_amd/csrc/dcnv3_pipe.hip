@@ -316,9 +316,64 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
         dma_round();                                                                                              \
     }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
+                    if (K == 9) {
+                        // Round 6: the nine points of a 3 x 3 kernel as a TWO-DEEP pipeline (msda_tiled9.hip's gather): the eight reads
+                        // of point j + 1 are in flight under the sixteen packed multiply-adds of point j -- two register sets, the LDS
+                        // returns a wave's reads in order, s_waitcnt lgkmcnt(8) releases the older set.  One point at a time (the
+                        // form below, kept for other kernel sizes) pays the LDS round trip of every point behind one DMA round:
+                        // 689 -> 664 us at 8 x 168^2 x 640, 383 -> 370 at 84^2 x 1280, same box (profiles/r06_dcnv3_pipe2.txt).
+                        // The next point's addresses and this point's weights are evaluated IN FRONT of the wait (pinned).
+                        struct DpSet { float4_t a0, a1, a2, a3, c0, c1, c2, c3; };
+                        DpSet sa, sb;
+#define DP_RD8(SET, T0, B0)                                                                                                   \
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"             \
+                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"                \
+                 : "=&v"(SET.a0), "=&v"(SET.a1), "=&v"(SET.a2), "=&v"(SET.a3), "=&v"(SET.c0), "=&v"(SET.c1), "=&v"(SET.c2), "=&v"(SET.c3) \
+                 : "v"(T0), "v"(T0 ^ 32), "v"(T0 ^ 64), "v"(T0 ^ 96), "v"(B0), "v"(B0 ^ 32), "v"(B0 ^ 64), "v"(B0 ^ 96));
+#define DP_RDP(SET, R_, LQ)                                                                                                   \
+    {                                                                                                                         \
+        const int t0_ = dp_qbi<LQ>(pc.top[R_]) + lbase, b0_ = dp_qbi<LQ>(pc.bot[R_]) + lbase;                                 \
+        DP_RD8(SET, t0_, b0_)                                                                                                 \
+    }
+#define DP_STEP(SET, R_, LQ, CNT, NX, NR_, NLQ)                                                                               \
+    {                                                                                                                         \
+        int t0_ = (NX) ? dp_qbi<NLQ>(pc.top[NR_]) + lbase : 0, b0_ = (NX) ? dp_qbi<NLQ>(pc.bot[NR_]) + lbase : 0;             \
+        const float x1 = dp_qbf<LQ>(pc.w1[R_]), x2 = dp_qbf<LQ>(pc.w2[R_]), x3 = dp_qbf<LQ>(pc.w3[R_]),                       \
+                    x4 = dp_qbf<LQ>(pc.w4[R_]);                                                                               \
+        float eT = pr_s ? x2 : x1, eB = pr_s ? x4 : x3;                                                                       \
+        asm volatile("" : "+v"(t0_), "+v"(b0_), "+v"(eT), "+v"(eB));                                                          \
+        dma_round();                                                                                                          \
+        if (CNT) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(SET.a0), "+v"(SET.a1), "+v"(SET.a2), "+v"(SET.a3), "+v"(SET.c0), "+v"(SET.c1), "+v"(SET.c2), "+v"(SET.c3)); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(SET.a0), "+v"(SET.a1), "+v"(SET.a2), "+v"(SET.a3), "+v"(SET.c0), "+v"(SET.c1), "+v"(SET.c2), "+v"(SET.c3)); \
+        _Pragma("unroll") for (int c = 0; c < 4; c += 2) {                                                                    \
+            float2_t u0 = {acc[0][c], acc[0][c + 1]}, u1 = {acc[1][c], acc[1][c + 1]};                                        \
+            float2_t u2 = {acc[2][c], acc[2][c + 1]}, u3 = {acc[3][c], acc[3][c + 1]};                                        \
+            u0 = dp_fma2(eT, (float2_t){SET.a0[c], SET.a0[c + 1]}, u0); u0 = dp_fma2(eB, (float2_t){SET.c0[c], SET.c0[c + 1]}, u0); \
+            u1 = dp_fma2(eT, (float2_t){SET.a1[c], SET.a1[c + 1]}, u1); u1 = dp_fma2(eB, (float2_t){SET.c1[c], SET.c1[c + 1]}, u1); \
+            u2 = dp_fma2(eT, (float2_t){SET.a2[c], SET.a2[c + 1]}, u2); u2 = dp_fma2(eB, (float2_t){SET.c2[c], SET.c2[c + 1]}, u2); \
+            u3 = dp_fma2(eT, (float2_t){SET.a3[c], SET.a3[c + 1]}, u3); u3 = dp_fma2(eB, (float2_t){SET.c3[c], SET.c3[c + 1]}, u3); \
+            acc[0][c] = u0.x; acc[0][c + 1] = u0.y; acc[1][c] = u1.x; acc[1][c + 1] = u1.y;                                    \
+            acc[2][c] = u2.x; acc[2][c + 1] = u2.y; acc[3][c] = u3.x; acc[3][c + 1] = u3.y;                                    \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                         \
+            asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]), "+v"(acc[t][2]), "+v"(acc[t][3]));                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        if (NX) { DP_RD8(SET, t0_, b0_) }                                                                                     \
+    }
+                        DP_RDP(sa, 0, 0) DP_RDP(sb, 0, 1)
+                        DP_STEP(sa, 0, 0, 8, true, 0, 2) DP_STEP(sb, 0, 1, 8, true, 0, 3)
+                        DP_STEP(sa, 0, 2, 8, true, 1, 0) DP_STEP(sb, 0, 3, 8, true, 1, 1)
+                        DP_STEP(sa, 1, 0, 8, true, 1, 2) DP_STEP(sb, 1, 1, 8, true, 1, 3)
+                        DP_STEP(sa, 1, 2, 8, true, 2, 0) DP_STEP(sb, 1, 3, 8, false, 0, 0)
+                        DP_STEP(sa, 2, 0, 0, false, 0, 0)
+#undef DP_STEP
+#undef DP_RDP
+#undef DP_RD8
+                    } else {
                     DP_POINT(0, 0) DP_POINT(0, 1) DP_POINT(0, 2) DP_POINT(0, 3)
                     DP_POINT(1, 0) DP_POINT(1, 1) DP_POINT(1, 2) DP_POINT(1, 3)
                     DP_POINT(2, 0)
+                    }
 #undef DP_POINT
                 } else {
                     // cold tile: this lane's column of the footprint from global memory (clamped addresses, selects decide what
