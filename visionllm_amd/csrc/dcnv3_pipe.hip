@@ -6,7 +6,8 @@
 // What the phase clock of the two-blocks-per-CU kernel (dcnv3_tiled.hip, profiles/r02_dcnv3_tiled.txt) showed: 40 % of a
 // block's time is issuing / waiting for the window DMA, 14 % the box barrier, 12 % point arithmetic that waits for its
 // offsets; only the other block of the CU fills those gaps, and the point table costs 18 KB of LDS and two LDS reads per
-// point.  Here ONE block of 8 waves owns the CU, a tile is 8 x 16 output pixels of one (image, group), a quad per pixel:
+// point.  Here a block is software-pipelined across its tiles (rounds 2-5: ONE block of 8 waves per CU on 8 x 16 tiles;
+// round 6: two blocks of 4 waves on 8 x 8 tiles, see DP_TH below); a tile is a rectangle of output pixels of one (image, group), a quad per pixel:
 //   * no table: quad lane k evaluates points k, k + 4, k + 8 of its pixel (from offsets / mask values requested TWO tiles
 //     ahead) and keeps {top corner offset, bottom corner offset, 4 weights x mask} in registers; the gather broadcasts them
 //     within the quad by DPP;
@@ -30,7 +31,13 @@ __device__ unsigned long long g_dp_prof[16];
         tprev = now__;                                                           \
     }
 
-constexpr int DP_TH = 8, DP_TW = 16, DP_NPX = DP_TH * DP_TW, DP_THREADS = DP_NPX * 4, DP_WAVES = DP_THREADS / 64;
+// Round 6: 8 x 8 tiles, four waves per block, half-size windows (300 pixels at 32 channels) and TWO blocks per CU instead of one block
+// of eight waves on 8 x 16 tiles: the same 8 waves per CU and the same registers, but the two blocks drift apart, so one block's
+// gather (LDS) runs next to the other's point arithmetic / window geometry (VALU) -- phases that all eight waves of the single block
+// went through in step (57 % of its time outside the gather, profiles/r06_dcnv3_pipe2.txt).  Same box: 8 x 168^2 x 640: 673 -> 629 us,
+// 84^2 x 1280: 374 -> 323; 8 x 4 tiles at four blocks per CU (144-pixel windows: most tiles no longer fit): 1198 us.
+constexpr int DP_TH = 8, DP_TW = 8, DP_NPX = DP_TH * DP_TW, DP_THREADS = DP_NPX * 4, DP_WAVES = DP_THREADS / 64;
+constexpr int DP_BPC = 2;   // blocks per CU
 constexpr int DP_BIG = 0x3fffffff;
 
 // value of quad lane K (DPP quad_perm broadcast)
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(DP_THREADS, 2) void dcnv3_fwd_pipe_kernel(const flo
 
     // per-lane constants
     const int k = tid & 3, pix = tid >> 2;                 // quad lane, pixel of the tile
-    const int py = pix >> 4, px = pix & 15;
+    const int py = pix / DP_TW, px = pix % DP_TW;
     const int so = k * 16;                                  // this lane's 16 bytes inside each 64-byte half of a pixel row
     const int sub = lane % LPP, lpx = lane / LPP;          // DMA roles
     const int p0w_i = ((q.dw * (q.kw - 1)) >> 1) - q.pw, p0h_i = ((q.dh * (q.kh - 1)) >> 1) - q.ph;
@@ -544,7 +551,7 @@ int dp_go(const float *in, const float *off, const float *msk, const Dcnv3Geo &q
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_fwd_pipe_kernel<CPG, WIN, PROF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    VLLM_LAUNCH((dcnv3_fwd_pipe_kernel<CPG, WIN, PROF>), dim3((unsigned)((cus / 8) * 8)), dim3(DP_THREADS), lds, st, in, off, msk, out,
+    VLLM_LAUNCH((dcnv3_fwd_pipe_kernel<CPG, WIN, PROF>), dim3((unsigned)((cus / 8) * 8 * DP_BPC)), dim3(DP_THREADS), lds, st, in, off, msk, out,
                 q, offset_scale);
     VLLM_CHECK_LAUNCH("dcnv3_fwd_pipe_kernel");
     return VLLM_OK;
@@ -563,8 +570,9 @@ int dcnv3_pipe_launch(const float *in, const float *off, const float *msk, const
                       hipStream_t st)
 {
     if ((long)q.N * q.Ho * q.Wo * q.G == 0) return VLLM_OK;
-    if (q.C == 32) return prof ? dp_go<32, 620, true>(in, off, msk, q, offset_scale, out, st) : dp_go<32, 620, false>(in, off, msk, q, offset_scale, out, st);
-    return prof ? dp_go<16, 1240, true>(in, off, msk, q, offset_scale, out, st) : dp_go<16, 1240, false>(in, off, msk, q, offset_scale, out, st);
+    constexpr int W32 = 300, W16 = 600;   // window pixels per buffer: 2 x (300 + 8) x 128 B = 77 KiB per block
+    if (q.C == 32) return prof ? dp_go<32, W32, true>(in, off, msk, q, offset_scale, out, st) : dp_go<32, W32, false>(in, off, msk, q, offset_scale, out, st);
+    return prof ? dp_go<16, W16, true>(in, off, msk, q, offset_scale, out, st) : dp_go<16, W16, false>(in, off, msk, q, offset_scale, out, st);
 }
 
 int dcnv3_pipe_debug_counters(long *out, int n)
